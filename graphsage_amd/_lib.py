@@ -1,0 +1,77 @@
+"""ctypes binding of libsage_hip.so (the C ABI declared in include/sage_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised (the convention of the natives the reference binds through
+torch.ops, e.g. samplers/uniform_loader.py:64).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsage_hip.so")
+
+# name -> (restype, argtypes); mirrors include/sage_hip.h declaration by declaration.
+_P = c_void_p
+SIGNATURES = {
+    "sage_last_error": (c_char_p, []),
+    "sage_abi_version": (c_int, []),
+    "sage_csc_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sage_csc_build": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P]),
+    "sage_sample_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sage_sample_fanout": (c_int, [_P, _P, c_int64, _P, c_int, ctypes.POINTER(c_int), c_int,
+                                   c_uint64, c_uint64, _P, c_uint32, c_int64, c_int64,
+                                   _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "sage_random_neighbor": (c_int, [_P, _P, _P, c_int64, c_uint64, c_uint64, _P, _P]),
+    "sage_gather_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, c_int64, _P]),
+    "sage_gather_reduce_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int,
+                                       _P, c_int64, _P, _P]),
+    "sage_gather_reduce_bwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int,
+                                       _P, c_int64, _P]),
+    "sage_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "sage_coo_to_csr": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P]),
+    "sage_linear_concat_fwd": (c_int, [_P, c_int64, _P, c_int, _P, c_int64,
+                                       _P, c_int64, _P, c_int, _P, c_int64,
+                                       _P, c_int, c_int64, _P, c_int, _P, c_int64, _P]),
+    "sage_linear_dinput": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int, c_int,
+                                   _P, c_int64, c_int, _P]),
+    "sage_linear_dweight": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int, c_int,
+                                    _P, c_int64, _P, _P]),
+    "sage_l2norm_relu_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int, _P, c_int64, _P, c_int64,
+                                     _P, _P]),
+    "sage_l2norm_relu_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int64, _P, c_int,
+                                     _P, c_int64, _P]),
+    "sage_softmax_xent": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, c_int64,
+                                  _P]),
+    "sage_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
+                               c_float, c_float, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libsage_hip.so once; raise RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C graphsage_amd/csrc` "
+            "(or __graft_entry__.build()); graphsage_amd has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> a symbol the header declares is missing
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sage_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,530 @@
+// (a-3) row gather and (a-5) fused gather + segment reduce, forward and backward.
+//
+// Replaces, without materialising the per-edge tensor x_j:
+//   filter_data's index_select          reference samplers/uniform_loader.py:238-239
+//   SAGE.message  x_j = x[edge_index[0]] reference layers/sage.py:136-137
+//   torch_scatter.scatter(x_j, edge_index[1], reduce)  reference layers/sage.py:209-210
+//
+// Shape of the work (Reddit 25/10, B=512): ~13 k targets with <= 25 / <= 10 neighbours,
+// rows of 602 fp32 = 2,408 B read at random from a 561 MB table.  HBM-bound, ~0.25
+// flop/byte.  One 64-lane wavefront owns one target: the segment's neighbour ids are
+// loaded once by the lanes (one id per lane) and broadcast with v_readlane, so every
+// row's base address is wave-uniform and each lane issues 16-byte loads at
+// base + 16*lane; ROWS_IN_FLIGHT rows are requested before the first is consumed.  The
+// reduction over the segment happens in registers (each lane owns the same feature
+// columns of every row), so the forward needs no atomics and no LDS.
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "common.h"
+
+namespace sage {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kRowsInFlight = 4;
+
+template <int VEC>
+struct VecT;
+template <>
+struct VecT<4> {
+  using type = float4;
+};
+template <>
+struct VecT<2> {
+  using type = float2;
+};
+template <>
+struct VecT<1> {
+  using type = float;
+};
+
+template <int VEC>
+__device__ inline void vec_to_arr(const typename VecT<VEC>::type& v, float* a);
+template <>
+__device__ inline void vec_to_arr<4>(const float4& v, float* a) {
+  a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+}
+template <>
+__device__ inline void vec_to_arr<2>(const float2& v, float* a) {
+  a[0] = v.x; a[1] = v.y;
+}
+template <>
+__device__ inline void vec_to_arr<1>(const float& v, float* a) {
+  a[0] = v;
+}
+template <int VEC>
+__device__ inline typename VecT<VEC>::type arr_to_vec(const float* a);
+template <>
+__device__ inline float4 arr_to_vec<4>(const float* a) {
+  return make_float4(a[0], a[1], a[2], a[3]);
+}
+template <>
+__device__ inline float2 arr_to_vec<2>(const float* a) {
+  return make_float2(a[0], a[1]);
+}
+template <>
+__device__ inline float arr_to_vec<1>(const float* a) {
+  return a[0];
+}
+
+__device__ inline int64_t readlane64(int64_t v, int lane) {
+  uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), lane);
+  uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(static_cast<uint64_t>(v) >> 32), lane);
+  return static_cast<int64_t>((static_cast<uint64_t>(hi) << 32) | lo);
+}
+
+// ---------------------------------------------------------------- gather rows
+// wide rows: one wave per group of kRowsInFlight rows
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+gather_rows_wide_kernel(const uint32_t* __restrict__ table, int64_t ld_table,
+                        const int64_t* __restrict__ index, int64_t num_rows,
+                        const int64_t* __restrict__ num_rows_dev, int width,
+                        uint32_t* __restrict__ out, int64_t ld_out) {
+  using V = typename VecT<VEC>::type;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t n = dev_count(num_rows_dev, num_rows);
+  const int64_t wave_id = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  const int64_t r0 = wave_id * kRowsInFlight;
+  if (r0 >= n) return;
+  const int nr = (n - r0) < kRowsInFlight ? static_cast<int>(n - r0) : kRowsInFlight;
+  int64_t my = 0;
+  if (lane < nr) my = index[r0 + lane];
+  const int nvec = (width + VEC - 1) / VEC;  // a ragged last vector stays inside the row stride
+  for (int c = lane; c < nvec; c += kWave) {
+    V v[kRowsInFlight];
+#pragma unroll
+    for (int r = 0; r < kRowsInFlight; ++r) {
+      if (r < nr) {
+        const int64_t rowid = readlane64(my, r);
+        v[r] = reinterpret_cast<const V*>(table + rowid * ld_table)[c];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsInFlight; ++r) {
+      if (r < nr) reinterpret_cast<V*>(out + (r0 + r) * ld_out)[c] = v[r];
+    }
+  }
+}
+
+// narrow rows (labels, ids): one thread per 32-bit word
+__global__ void gather_rows_narrow_kernel(const uint32_t* __restrict__ table, int64_t ld_table,
+                                          const int64_t* __restrict__ index, int64_t num_rows,
+                                          const int64_t* __restrict__ num_rows_dev, int width,
+                                          uint32_t* __restrict__ out, int64_t ld_out) {
+  const int64_t n = dev_count(num_rows_dev, num_rows);
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t r = i / width;
+  const int w = static_cast<int>(i - r * width);
+  if (r >= n) return;
+  out[r * ld_out + w] = table[index[r] * ld_table + w];
+}
+
+// ---------------------------------------------------------------- gather + segment reduce
+// One wave per (target, feature slab).  A slab is 64*VEC*NV consecutive features.
+template <int VEC, int NV, int REDUCE>
+__global__ void __launch_bounds__(kBlock)
+gather_reduce_fwd_kernel(const float* __restrict__ x, int64_t ld_x,
+                         const int64_t* __restrict__ node_map,
+                         const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src,
+                         int64_t num_targets, const int64_t* __restrict__ num_targets_dev,
+                         int num_features, float* __restrict__ out, int64_t ld_out,
+                         int64_t* __restrict__ argmax) {
+  using V = typename VecT<VEC>::type;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (t >= nt) return;
+  const int slab0 = blockIdx.y * (kWave * VEC * NV);  // first feature of this slab
+  const int64_t s0 = seg_ptr[t];
+  const int64_t s1 = seg_ptr[t + 1];
+  const int64_t len = s1 - s0;
+
+  // feature column owned by this lane in chunk c: slab0 + (c*64 + lane)*VEC
+  bool live[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) live[c] = slab0 + (c * kWave + lane) * VEC < num_features;
+
+  float acc[NV][VEC];
+  int arg[NV][VEC];  // max only: edge offset (relative to s0) that supplied the maximum
+#pragma unroll
+  for (int c = 0; c < NV; ++c)
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      acc[c][j] = 0.f;
+      arg[c][j] = -1;
+    }
+
+  for (int64_t base = 0; base < len; base += kWave) {
+    const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
+    int64_t my = 0;
+    if (lane < chunk) {
+      my = src[s0 + base + lane];
+      if (node_map != nullptr) my = node_map[my];
+    }
+    for (int r0 = 0; r0 < chunk; r0 += kRowsInFlight) {
+      V v[kRowsInFlight][NV];
+#pragma unroll
+      for (int r = 0; r < kRowsInFlight; ++r) {
+        if (r0 + r < chunk) {
+          const int64_t rowid = readlane64(my, r0 + r);
+          const V* rowp = reinterpret_cast<const V*>(x + rowid * ld_x + slab0);
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            if (live[c]) v[r][c] = rowp[c * kWave + lane];
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRowsInFlight; ++r) {
+        if (r0 + r < chunk) {
+#pragma unroll
+          for (int c = 0; c < NV; ++c) {
+            float a[VEC];
+            vec_to_arr<VEC>(v[r][c], a);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+              if (REDUCE == SAGE_REDUCE_MAX) {
+                const int e = static_cast<int>(base) + r0 + r;
+                if (arg[c][j] < 0 || a[j] > acc[c][j]) {
+                  acc[c][j] = a[j];
+                  arg[c][j] = e;
+                }
+              } else {
+                acc[c][j] += a[j];
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  const float cnt = len > 0 ? static_cast<float>(len) : 1.f;
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    if (!live[c]) continue;
+    const int f = slab0 + (c * kWave + lane) * VEC;
+    float a[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      a[j] = (REDUCE == SAGE_REDUCE_MEAN) ? acc[c][j] / cnt : acc[c][j];
+    }
+    *reinterpret_cast<V*>(out + t * ld_out + f) = arr_to_vec<VEC>(a);
+    if (REDUCE == SAGE_REDUCE_MAX && argmax != nullptr) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (f + j < num_features) {
+          argmax[t * static_cast<int64_t>(num_features) + f + j] = arg[c][j] < 0 ? -1 : s0 + arg[c][j];
+        }
+      }
+    }
+  }
+}
+
+// Backward for sum/mean: one wave per target; lane owns columns lane, lane+64, ... so that
+// each atomic wave-instruction adds 256 contiguous bytes of one dx row.
+template <int NV>
+__global__ void __launch_bounds__(kBlock)
+gather_reduce_bwd_kernel(const float* __restrict__ dout, int64_t ld_dout,
+                         const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src,
+                         int64_t num_targets, const int64_t* __restrict__ num_targets_dev,
+                         int num_features, int mean, float* __restrict__ dx, int64_t ld_dx) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (t >= nt) return;
+  const int slab0 = blockIdx.y * (kWave * NV);
+  const int64_t s0 = seg_ptr[t];
+  const int64_t len = seg_ptr[t + 1] - s0;
+  if (len <= 0) return;
+  const float cnt = static_cast<float>(len);
+  float g[NV];
+#pragma unroll
+  for (int c = 0; c < NV; ++c) {
+    const int f = slab0 + c * kWave + lane;
+    g[c] = f < num_features ? dout[t * ld_dout + f] : 0.f;
+    if (mean) g[c] = g[c] / cnt;
+  }
+  for (int64_t base = 0; base < len; base += kWave) {
+    const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
+    int64_t my = 0;
+    if (lane < chunk) my = src[s0 + base + lane];
+    for (int r = 0; r < chunk; ++r) {
+      const int64_t rowid = readlane64(my, r);
+      float* rowp = dx + rowid * ld_dx + slab0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        if (slab0 + c * kWave + lane < num_features) atomicAdd(rowp + c * kWave + lane, g[c]);
+      }
+    }
+  }
+}
+
+// Backward for max: route dout[t,f] to the source row recorded in argmax.
+__global__ void gather_max_bwd_kernel(const float* __restrict__ dout, int64_t ld_dout,
+                                      const int64_t* __restrict__ src,
+                                      const int64_t* __restrict__ argmax, int64_t num_targets,
+                                      const int64_t* __restrict__ num_targets_dev,
+                                      int num_features, float* __restrict__ dx, int64_t ld_dx) {
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = blockIdx.x;
+  if (t >= nt) return;
+  for (int f = threadIdx.x; f < num_features; f += blockDim.x) {
+    const int64_t e = argmax[t * num_features + f];
+    if (e >= 0) atomicAdd(dx + src[e] * ld_dx + f, dout[t * ld_dout + f]);
+  }
+}
+
+// ---------------------------------------------------------------- COO -> target CSR
+__global__ void iota_hist_kernel(const int64_t* __restrict__ edge_dst, int64_t num_edges,
+                                 int64_t num_targets, int64_t* __restrict__ iota,
+                                 unsigned long long* __restrict__ counts) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= num_edges) return;
+  iota[e] = e;
+  const int64_t d = edge_dst[e];
+  if (d >= 0 && d < num_targets) atomicAdd(&counts[d], 1ull);
+}
+
+__global__ void permute_src_kernel(const int64_t* __restrict__ edge_src,
+                                   const int64_t* __restrict__ perm, int64_t num_edges,
+                                   int64_t* __restrict__ src_sorted) {
+  const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e < num_edges) src_sorted[e] = edge_src[perm[e]];
+}
+
+int bits_for(int64_t n) {
+  int b = 1;
+  while (b < 63 && (1ll << b) < n) ++b;
+  return b;
+}
+
+size_t sort_temp_bytes(size_t n, int bits) {
+  size_t bytes = 0;
+  int64_t* p = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, n, 0, bits, nullptr);
+  return bytes;
+}
+size_t scan64_temp_bytes(size_t n) {
+  size_t bytes = 0;
+  int64_t* p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, bytes, p, p, int64_t(0), n, rocprim::plus<int64_t>(), nullptr);
+  return bytes;
+}
+
+bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Widest vector width (in 32-bit words) usable for rows of `width` words starting at p with
+// stride ld.  A ragged last vector is allowed when it stays inside the row stride (the
+// caller pads rows, e.g. 602 -> 608 floats), so it never touches another row.
+int pick_vec(const void* p, int64_t ld, int width) {
+  if (aligned(p, 16) && ld % 4 == 0 && ld >= (width + 3) / 4 * 4) return 4;
+  if (aligned(p, 8) && ld % 2 == 0 && ld >= (width + 1) / 2 * 2) return 2;
+  return 1;
+}
+
+}  // namespace
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" int sage_gather_rows(const void* table, sage_i64 ld_table, const sage_i64* index,
+                                sage_i64 num_rows, const sage_i64* num_rows_dev, int width,
+                                void* out, sage_i64 ld_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(width > 0 && ld_table >= width && ld_out >= width && num_rows >= 0, SAGE_EINVAL,
+               "sage_gather_rows: bad shape (rows=%lld width=%d ld_table=%lld ld_out=%lld)",
+               (long long)num_rows, width, (long long)ld_table, (long long)ld_out);
+  if (num_rows == 0) return SAGE_OK;
+  SAGE_REQUIRE(table && index && out, SAGE_EINVAL, "sage_gather_rows: NULL pointer argument");
+  const uint32_t* tp = static_cast<const uint32_t*>(table);
+  uint32_t* op = static_cast<uint32_t*>(out);
+  if (width < 32) {
+    const int64_t total = num_rows * width;
+    gather_rows_narrow_kernel<<<static_cast<unsigned>(cdiv(total, kBlock)), kBlock, 0, stream>>>(
+        tp, ld_table, index, num_rows, num_rows_dev, width, op, ld_out);
+    SAGE_CHECK_LAUNCH("gather_rows_narrow_kernel");
+    return SAGE_OK;
+  }
+  int vec = pick_vec(table, ld_table, width);
+  const int vo = pick_vec(out, ld_out, width);
+  if (vo < vec) vec = vo;
+  const unsigned grid = static_cast<unsigned>(cdiv(cdiv(num_rows, kRowsInFlight), kWavesPerBlock));
+  if (vec == 4) {
+    gather_rows_wide_kernel<4><<<grid, kBlock, 0, stream>>>(tp, ld_table, index, num_rows,
+                                                            num_rows_dev, width, op, ld_out);
+  } else if (vec == 2) {
+    gather_rows_wide_kernel<2><<<grid, kBlock, 0, stream>>>(tp, ld_table, index, num_rows,
+                                                            num_rows_dev, width, op, ld_out);
+  } else {
+    gather_rows_wide_kernel<1><<<grid, kBlock, 0, stream>>>(tp, ld_table, index, num_rows,
+                                                            num_rows_dev, width, op, ld_out);
+  }
+  SAGE_CHECK_LAUNCH("gather_rows_wide_kernel");
+  return SAGE_OK;
+}
+
+namespace {
+
+template <int VEC, int NV>
+int launch_fwd(const float* x, int64_t ld_x, const int64_t* node_map, const int64_t* seg_ptr,
+               const int64_t* src, int64_t nt, const int64_t* nt_dev, int nf, int reduce,
+               float* out, int64_t ld_out, int64_t* argmax, hipStream_t stream) {
+  dim3 grid(static_cast<unsigned>(cdiv(nt, kWavesPerBlock)),
+            static_cast<unsigned>(cdiv(nf, kWave * VEC * NV)));
+  if (reduce == SAGE_REDUCE_MEAN) {
+    gather_reduce_fwd_kernel<VEC, NV, SAGE_REDUCE_MEAN><<<grid, kBlock, 0, stream>>>(
+        x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, out, ld_out, argmax);
+  } else if (reduce == SAGE_REDUCE_SUM) {
+    gather_reduce_fwd_kernel<VEC, NV, SAGE_REDUCE_SUM><<<grid, kBlock, 0, stream>>>(
+        x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, out, ld_out, argmax);
+  } else {
+    gather_reduce_fwd_kernel<VEC, NV, SAGE_REDUCE_MAX><<<grid, kBlock, 0, stream>>>(
+        x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, out, ld_out, argmax);
+  }
+  SAGE_CHECK_LAUNCH("gather_reduce_fwd_kernel");
+  return SAGE_OK;
+}
+
+template <int VEC>
+int dispatch_fwd_nv(int nv, const float* x, int64_t ld_x, const int64_t* node_map,
+                    const int64_t* seg_ptr, const int64_t* src, int64_t nt, const int64_t* nt_dev,
+                    int nf, int reduce, float* out, int64_t ld_out, int64_t* argmax,
+                    hipStream_t stream) {
+  switch (nv) {
+    case 1:
+      return launch_fwd<VEC, 1>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+    case 2:
+      return launch_fwd<VEC, 2>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+    case 3:
+      return launch_fwd<VEC, 3>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+    default:
+      return launch_fwd<VEC, 4>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+  }
+}
+
+}  // namespace
+
+extern "C" int sage_gather_reduce_fwd(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                                      const sage_i64* seg_ptr, const sage_i64* src,
+                                      sage_i64 num_targets, const sage_i64* num_targets_dev,
+                                      int num_features, int reduce, float* out, sage_i64 ld_out,
+                                      sage_i64* argmax, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX,
+               SAGE_EINVAL, "sage_gather_reduce_fwd: unknown reduce %d", reduce);
+  SAGE_REQUIRE(num_features > 0 && ld_x >= num_features && ld_out >= num_features && num_targets >= 0,
+               SAGE_EINVAL, "sage_gather_reduce_fwd: bad shape (T=%lld F=%d ld_x=%lld ld_out=%lld)",
+               (long long)num_targets, num_features, (long long)ld_x, (long long)ld_out);
+  if (num_targets == 0) return SAGE_OK;
+  SAGE_REQUIRE(x && seg_ptr && src && out, SAGE_EINVAL, "sage_gather_reduce_fwd: NULL pointer argument");
+  int vec = pick_vec(x, ld_x, num_features);
+  const int vo = pick_vec(out, ld_out, num_features);
+  if (vo < vec) vec = vo;
+  const int per = kWave * vec;
+  int nv = static_cast<int>(cdiv(num_features, per));
+  if (nv > 4) nv = 4;
+  if (vec == 4)
+    return dispatch_fwd_nv<4>(nv, x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
+                              num_features, reduce, out, ld_out, argmax, stream);
+  if (vec == 2)
+    return dispatch_fwd_nv<2>(nv, x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
+                              num_features, reduce, out, ld_out, argmax, stream);
+  return dispatch_fwd_nv<1>(nv, x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
+                            num_features, reduce, out, ld_out, argmax, stream);
+}
+
+extern "C" int sage_gather_reduce_bwd(const float* dout, sage_i64 ld_dout, const sage_i64* seg_ptr,
+                                      const sage_i64* src, const sage_i64* argmax,
+                                      sage_i64 num_targets, const sage_i64* num_targets_dev,
+                                      int num_features, int reduce, float* dx, sage_i64 ld_dx,
+                                      void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX,
+               SAGE_EINVAL, "sage_gather_reduce_bwd: unknown reduce %d", reduce);
+  SAGE_REQUIRE(num_features > 0 && ld_dout >= num_features && ld_dx >= num_features && num_targets >= 0,
+               SAGE_EINVAL, "sage_gather_reduce_bwd: bad shape");
+  if (num_targets == 0) return SAGE_OK;
+  SAGE_REQUIRE(dout && seg_ptr && src && dx, SAGE_EINVAL, "sage_gather_reduce_bwd: NULL pointer argument");
+  if (reduce == SAGE_REDUCE_MAX) {
+    SAGE_REQUIRE(argmax != nullptr, SAGE_EINVAL, "sage_gather_reduce_bwd: max needs argmax");
+    gather_max_bwd_kernel<<<static_cast<unsigned>(num_targets), kBlock, 0, stream>>>(
+        dout, ld_dout, src, argmax, num_targets, num_targets_dev, num_features, dx, ld_dx);
+    SAGE_CHECK_LAUNCH("gather_max_bwd_kernel");
+    return SAGE_OK;
+  }
+  const int mean = reduce == SAGE_REDUCE_MEAN;
+  int nv = static_cast<int>(cdiv(num_features, kWave));
+  if (nv > 4) nv = 4;
+  dim3 grid(static_cast<unsigned>(cdiv(num_targets, kWavesPerBlock)),
+            static_cast<unsigned>(cdiv(num_features, kWave * nv)));
+  switch (nv) {
+    case 1:
+      gather_reduce_bwd_kernel<1><<<grid, kBlock, 0, stream>>>(dout, ld_dout, seg_ptr, src, num_targets, num_targets_dev, num_features, mean, dx, ld_dx);
+      break;
+    case 2:
+      gather_reduce_bwd_kernel<2><<<grid, kBlock, 0, stream>>>(dout, ld_dout, seg_ptr, src, num_targets, num_targets_dev, num_features, mean, dx, ld_dx);
+      break;
+    case 3:
+      gather_reduce_bwd_kernel<3><<<grid, kBlock, 0, stream>>>(dout, ld_dout, seg_ptr, src, num_targets, num_targets_dev, num_features, mean, dx, ld_dx);
+      break;
+    default:
+      gather_reduce_bwd_kernel<4><<<grid, kBlock, 0, stream>>>(dout, ld_dout, seg_ptr, src, num_targets, num_targets_dev, num_features, mean, dx, ld_dx);
+      break;
+  }
+  SAGE_CHECK_LAUNCH("gather_reduce_bwd_kernel");
+  return SAGE_OK;
+}
+
+extern "C" size_t sage_coo_to_csr_workspace_bytes(sage_i64 num_edges, sage_i64 num_targets) {
+  if (num_edges < 0 || num_targets < 0) return 0;
+  size_t total = 0;
+  total += 2 * align_up(sizeof(int64_t) * (static_cast<size_t>(num_edges) + 1), 256);  // iota, keys_out
+  total += align_up(sizeof(int64_t) * (static_cast<size_t>(num_targets) + 2), 256);  // counts
+  total += align_up(sort_temp_bytes(static_cast<size_t>(num_edges) + 1, bits_for(num_targets + 1)), 256);
+  total += align_up(scan64_temp_bytes(static_cast<size_t>(num_targets) + 2), 256);
+  return total + 256;
+}
+
+extern "C" int sage_coo_to_csr(const sage_i64* edge_src, const sage_i64* edge_dst,
+                               sage_i64 num_edges, sage_i64 num_targets, sage_i64* seg_ptr,
+                               sage_i64* src_sorted, sage_i64* perm, void* workspace,
+                               size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(num_edges >= 0 && num_targets >= 0, SAGE_EINVAL, "sage_coo_to_csr: negative size");
+  SAGE_REQUIRE(seg_ptr && workspace, SAGE_EINVAL, "sage_coo_to_csr: NULL pointer argument");
+  SAGE_REQUIRE(workspace_bytes >= sage_coo_to_csr_workspace_bytes(num_edges, num_targets),
+               SAGE_EWORKSPACE, "sage_coo_to_csr: workspace too small");
+  Carver ws(workspace);
+  int64_t* iota = ws.take<int64_t>(num_edges + 1);
+  int64_t* keys_out = ws.take<int64_t>(num_edges + 1);
+  int64_t* counts = ws.take<int64_t>(num_targets + 2);
+  const int bits = bits_for(num_targets + 1);
+  size_t sort_bytes = sort_temp_bytes(static_cast<size_t>(num_edges) + 1, bits);
+  void* sort_tmp = ws.take<char>(sort_bytes);
+  size_t scan_bytes = scan64_temp_bytes(static_cast<size_t>(num_targets) + 2);
+  void* scan_tmp = ws.take<char>(scan_bytes);
+
+  SAGE_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (num_targets + 1), stream), "counts memset");
+  if (num_edges > 0) {
+    SAGE_REQUIRE(edge_src && edge_dst && src_sorted && perm, SAGE_EINVAL,
+                 "sage_coo_to_csr: NULL pointer argument");
+    iota_hist_kernel<<<static_cast<unsigned>(cdiv(num_edges, kBlock)), kBlock, 0, stream>>>(
+        edge_dst, num_edges, num_targets, iota, reinterpret_cast<unsigned long long*>(counts));
+    SAGE_CHECK_LAUNCH("iota_hist_kernel");
+    SAGE_CHECK_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, edge_dst, keys_out, iota, perm,
+                                             static_cast<size_t>(num_edges), 0, bits, stream),
+                   "radix_sort_pairs");
+    permute_src_kernel<<<static_cast<unsigned>(cdiv(num_edges, kBlock)), kBlock, 0, stream>>>(
+        edge_src, perm, num_edges, src_sorted);
+    SAGE_CHECK_LAUNCH("permute_src_kernel");
+  }
+  SAGE_CHECK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, counts, seg_ptr, int64_t(0),
+                                         static_cast<size_t>(num_targets + 1),
+                                         rocprim::plus<int64_t>(), stream),
+                 "scan(counts)");
+  return SAGE_OK;
+}

@@ -1,0 +1,394 @@
+// (a-4) self||neighbour Linear on the matrix cores, forward and backward.
+//
+// Replaces the two bias-free torch_geometric Linear calls of reference layers/sage.py:124-129
+// (out = lin_l(agg); out += lin_r(x_r)) by ONE contraction over the concatenated K
+// dimension [agg || x_r] . [W_l || W_r]^T, and the pool Linear (+bias, ReLU) of
+// layers/sage.py:76,202,206; the backward provides what autograd derives for them.
+//
+// Arithmetic is exact fp32 on the MFMA pipe: v_mfma_f32_32x32x2_f32 (gfx950 has no
+// xf32/TF32 path).  Every output element is an fp32 fma chain over k, so results agree
+// with an fp32 reference to summation-order rounding.
+//
+// One tile kernel serves the three contractions.  In "C[M][N] = sum_k A(m,k) B(k,n)" form:
+//   forward   : A(m,k) = a[rows(m)][k]   (k contiguous)   B(k,n) = w[n][k]   (k contiguous)
+//   d input   : A(m,k) = dout[m][k]      (k contiguous)   B(k,n) = w[k][n]   (n contiguous)
+//   d weight  : A(m,k) = dout[k][m]      (m contiguous)   B(k,n) = a[rows(k)][n]
+// Tiles are staged global -> registers -> LDS (k-major in LDS: As[k][m], Bs[k][n]), double
+// buffered, one barrier per K-step of 32; the MFMA fragment reads are then consecutive
+// addresses per lane (conflict-free ds_read_b32).  The optional row map lets the root
+// operand come straight out of the global feature table (no materialised batch.x).
+#include "common.h"
+
+namespace sage {
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kThreads = 256;
+constexpr int BK = 32;
+
+struct Operand {
+  const float* p;          // base pointer
+  int64_t ld;              // row stride in floats
+  const int64_t* rowmap;   // optional map applied to the operand's global row index
+  int vec;                 // widest safe vector width for its rows (4, 2 or 1)
+};
+
+struct Segment {
+  Operand a, b;
+  int k;  // contraction length of this segment
+};
+
+struct GemmArgs {
+  Segment seg[2];
+  int nseg;
+  int64_t m;               // rows of C (upper bound when m_dev != NULL)
+  const int64_t* m_dev;    // optional device-side row count (limits M)
+  const int64_t* k_dev;    // optional device-side contraction length (limits K of seg 0)
+  int n;                   // cols of C
+  float* out;
+  int64_t ld_out;
+  const float* bias;
+  int epilogue;            // SAGE_EPI_* flags
+  int atomic_out;          // 1: atomicAdd into out (split-K / accumulate)
+  int k_chunk;             // split-K: contraction elements per blockIdx.z (multiple of BK)
+  float* colsum;           // optional: colsum[m] += sum_k A(m,k) (dbias), only blockIdx.y == 0
+};
+
+// ---- global -> register staging of one operand tile ---------------------------------
+// KC  (contraction dim contiguous in memory): tile = MN rows x BK cols, row index = m/n.
+// !KC (m/n contiguous in memory):             tile = BK rows x MN cols, row index = k.
+template <bool KC, int MN>
+struct TileRegs {
+  float v[MN * BK / kThreads];
+};
+
+template <bool KC, int MN, int VEC>
+__device__ inline void load_tile(TileRegs<KC, MN>& r, const Operand& op, int64_t mn0,
+                                 int64_t mn_lim, int k0, int k_lim) {
+  constexpr int UNITS = MN * BK / VEC;  // vector units in the tile
+  constexpr int PASSES = UNITS / kThreads;
+  constexpr int UPR = (KC ? BK : MN) / VEC;  // units per tile row
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int u = threadIdx.x + p * kThreads;
+    const int trow = u / UPR;
+    const int tcol = (u % UPR) * VEC;
+    // global coordinates of the first element of this unit
+    const int64_t grow = KC ? (mn0 + trow) : static_cast<int64_t>(k0 + trow);
+    const int64_t gcol = KC ? static_cast<int64_t>(k0 + tcol) : (mn0 + tcol);
+    const int64_t row_lim = KC ? mn_lim : static_cast<int64_t>(k_lim);
+    const int64_t col_lim = KC ? static_cast<int64_t>(k_lim) : mn_lim;
+    float tmp[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) tmp[j] = 0.f;
+    if (grow < row_lim && gcol < col_lim) {
+      const int64_t mrow = op.rowmap != nullptr ? op.rowmap[grow] : grow;
+      const float* src = op.p + mrow * op.ld + gcol;
+      if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        tmp[0] = t.x; tmp[1] = t.y; tmp[2] = t.z; tmp[3] = t.w;
+      } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(src);
+        tmp[0] = t.x; tmp[1] = t.y;
+      } else {
+        tmp[0] = *src;
+      }
+      // a ragged last vector may read row padding: zero what lies beyond the limit
+#pragma unroll
+      for (int j = 1; j < VEC; ++j) {
+        if (gcol + j >= col_lim) tmp[j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) r.v[p * VEC + j] = tmp[j];
+  }
+}
+
+template <bool KC, int MN, int VEC, int LDS_LD>
+__device__ inline void store_tile(const TileRegs<KC, MN>& r, float* lds /*[BK][LDS_LD]*/) {
+  constexpr int UNITS = MN * BK / VEC;
+  constexpr int PASSES = UNITS / kThreads;
+  constexpr int UPR = (KC ? BK : MN) / VEC;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const int u = threadIdx.x + p * kThreads;
+    const int trow = u / UPR;
+    const int tcol = (u % UPR) * VEC;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (KC) {
+        lds[(tcol + j) * LDS_LD + trow] = r.v[p * VEC + j];  // transpose: [k][mn]
+      } else {
+        lds[trow * LDS_LD + tcol + j] = r.v[p * VEC + j];
+      }
+    }
+  }
+}
+
+template <bool KC, int MN>
+__device__ inline void load_tile_any(TileRegs<KC, MN>& r, const Operand& op, int64_t mn0,
+                                     int64_t mn_lim, int k0, int k_lim) {
+  if (op.vec == 4) load_tile<KC, MN, 4>(r, op, mn0, mn_lim, k0, k_lim);
+  else if (op.vec == 2) load_tile<KC, MN, 2>(r, op, mn0, mn_lim, k0, k_lim);
+  else load_tile<KC, MN, 1>(r, op, mn0, mn_lim, k0, k_lim);
+}
+template <bool KC, int MN, int LDS_LD>
+__device__ inline void store_tile_any(const TileRegs<KC, MN>& r, int vec, float* lds) {
+  if (vec == 4) store_tile<KC, MN, 4, LDS_LD>(r, lds);
+  else if (vec == 2) store_tile<KC, MN, 2, LDS_LD>(r, lds);
+  else store_tile<KC, MN, 1, LDS_LD>(r, lds);
+}
+
+// 4 waves as 2 (M) x 2 (N); each wave owns (BM/2) x (BN/2) = TM x TN tiles of 32x32.
+template <bool A_KC, bool B_KC, int BM, int BN>
+__global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int LDA = BM + (A_KC ? 2 : 4);
+  constexpr int LDB = BN + (B_KC ? 2 : 4);
+  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LDA + LDB)];
+  // layout: As[2][BK][LDA] then Bs[2][BK][LDB]
+  float* const As = lds;
+  float* const Bs = lds + 2 * BK * LDA;
+
+  int64_t m_lim = g.m;
+  if (g.m_dev != nullptr) {
+    const int64_t v = *g.m_dev;
+    if (v < m_lim) m_lim = v;
+  }
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
+  if (m0 >= m_lim) return;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.y) * BN;
+  const int64_t n_lim = g.n;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int wm0 = (wave >> 1) * (BM / 2);
+  const int wn0 = (wave & 1) * (BN / 2);
+  const int l31 = lane & 31;
+  const int half = lane >> 5;
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  float csum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) csum[i] = 0.f;
+
+  TileRegs<A_KC, BM> ra;
+  TileRegs<B_KC, BN> rb;
+
+  for (int s = 0; s < g.nseg; ++s) {
+    const Segment& sg = g.seg[s];
+    int k_lim = sg.k;
+    if (s == 0 && g.k_dev != nullptr) {
+      const int64_t v = *g.k_dev;
+      if (v < k_lim) k_lim = static_cast<int>(v);
+    }
+    int k_beg = 0, k_end = k_lim;
+    if (g.k_chunk > 0) {
+      k_beg = blockIdx.z * g.k_chunk;
+      k_end = k_beg + g.k_chunk < k_lim ? k_beg + g.k_chunk : k_lim;
+    }
+    if (k_beg >= k_end) continue;
+
+    int cur = 0;
+    load_tile_any<A_KC, BM>(ra, sg.a, m0, m_lim, k_beg, k_end);
+    load_tile_any<B_KC, BN>(rb, sg.b, n0, n_lim, k_beg, k_end);
+    __syncthreads();  // previous segment's readers are done with the buffers
+    store_tile_any<A_KC, BM, LDA>(ra, sg.a.vec, As);
+    store_tile_any<B_KC, BN, LDB>(rb, sg.b.vec, Bs);
+    __syncthreads();
+
+    for (int k0 = k_beg; k0 < k_end; k0 += BK) {
+      const bool has_next = k0 + BK < k_end;
+      if (has_next) {
+        load_tile_any<A_KC, BM>(ra, sg.a, m0, m_lim, k0 + BK, k_end);
+        load_tile_any<B_KC, BN>(rb, sg.b, n0, n_lim, k0 + BK, k_end);
+      }
+      const float* as = As + cur * (BK * LDA);
+      const float* bs = Bs + cur * (BK * LDB);
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        float af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = as[(kk + half) * LDA + wm0 + i * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = bs[(kk + half) * LDB + wn0 + j * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          csum[i] += af[i];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+      if (has_next) {
+        store_tile_any<A_KC, BM, LDA>(ra, sg.a.vec, As + (cur ^ 1) * (BK * LDA));
+        store_tile_any<B_KC, BN, LDB>(rb, sg.b.vec, Bs + (cur ^ 1) * (BK * LDB));
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3)+8*(e>>2)+4*half
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn0 + j * 32 + l31;
+      if (col >= n_lim) continue;
+      const float bv = (g.epilogue & SAGE_EPI_BIAS) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (row >= m_lim) continue;
+        float v = acc[i][j][e] + bv;
+        if (g.epilogue & SAGE_EPI_RELU) v = v > 0.f ? v : 0.f;
+        float* dst = g.out + row * g.ld_out + col;
+        if (g.atomic_out) atomicAdd(dst, v);
+        else *dst = v;
+      }
+    }
+  }
+  if (g.colsum != nullptr && blockIdx.y == 0 && (wave & 1) == 0) {
+    // lanes 0-31 summed even k, lanes 32-63 odd k of row (wm0 + i*32 + l31)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float tot = csum[i] + __shfl_xor(csum[i], 32);
+      const int64_t row = m0 + wm0 + i * 32 + l31;
+      if (half == 0 && row < m_lim) atomicAdd(g.colsum + row, tot);
+    }
+  }
+}
+
+bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Widest vector (floats) for loading `width` contiguous floats per row of stride ld,
+// starting at multiples of BK (row-contiguous dim = contraction) or of 64 (m/n).
+int op_vec(const float* p, int64_t ld, int64_t width) {
+  if (aligned(p, 16) && ld % 4 == 0 && ld >= (width + 3) / 4 * 4) return 4;
+  if (aligned(p, 8) && ld % 2 == 0 && ld >= (width + 1) / 2 * 2) return 2;
+  return 1;
+}
+
+template <bool A_KC, bool B_KC>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream, const char* what) {
+  if (g.m <= 0 || g.n <= 0) return SAGE_OK;
+  if (g.n > 64) {
+    dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)), static_cast<unsigned>(cdiv(g.n, 128)),
+              static_cast<unsigned>(splits));
+    gemm_kernel<A_KC, B_KC, 64, 128><<<grid, kThreads, 0, stream>>>(g);
+  } else {
+    dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)), static_cast<unsigned>(cdiv(g.n, 64)),
+              static_cast<unsigned>(splits));
+    gemm_kernel<A_KC, B_KC, 64, 64><<<grid, kThreads, 0, stream>>>(g);
+  }
+  SAGE_CHECK_LAUNCH(what);
+  return SAGE_OK;
+}
+
+}  // namespace
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sage_i64* rows1,
+                                      int k1, const float* w1, sage_i64 ld_w1, const float* a2,
+                                      sage_i64 ld_a2, const sage_i64* rows2, int k2,
+                                      const float* w2, sage_i64 ld_w2, const float* bias,
+                                      int epilogue, sage_i64 m, const sage_i64* m_dev, int n,
+                                      float* out, sage_i64 ld_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && k1 > 0 && k2 >= 0 && ld_out >= n, SAGE_EINVAL,
+               "sage_linear_concat_fwd: bad shape (m=%lld n=%d k1=%d k2=%d)", (long long)m, n, k1, k2);
+  SAGE_REQUIRE(ld_a1 >= k1 && ld_w1 >= k1 && (k2 == 0 || (ld_a2 >= k2 && ld_w2 >= k2)), SAGE_EINVAL,
+               "sage_linear_concat_fwd: row stride smaller than k");
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(a1 && w1 && out && (k2 == 0 || (a2 && w2)), SAGE_EINVAL,
+               "sage_linear_concat_fwd: NULL pointer argument");
+  SAGE_REQUIRE(!(epilogue & SAGE_EPI_BIAS) || bias != nullptr, SAGE_EINVAL,
+               "sage_linear_concat_fwd: SAGE_EPI_BIAS without bias");
+  GemmArgs g = {};
+  g.seg[0].a = {a1, ld_a1, rows1, op_vec(a1, ld_a1, k1)};
+  g.seg[0].b = {w1, ld_w1, nullptr, op_vec(w1, ld_w1, k1)};
+  g.seg[0].k = k1;
+  g.nseg = 1;
+  if (k2 > 0) {
+    g.seg[1].a = {a2, ld_a2, rows2, op_vec(a2, ld_a2, k2)};
+    g.seg[1].b = {w2, ld_w2, nullptr, op_vec(w2, ld_w2, k2)};
+    g.seg[1].k = k2;
+    g.nseg = 2;
+  }
+  g.m = m;
+  g.m_dev = m_dev;
+  g.n = n;
+  g.out = out;
+  g.ld_out = ld_out;
+  g.bias = bias;
+  g.epilogue = epilogue;
+  return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");
+}
+
+extern "C" int sage_linear_dinput(const float* dout, sage_i64 ld_dout, const float* w,
+                                  sage_i64 ld_w, sage_i64 m, const sage_i64* m_dev, int n, int k,
+                                  float* da, sage_i64 ld_da, int accumulate, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && k > 0 && ld_dout >= n && ld_w >= k && ld_da >= k, SAGE_EINVAL,
+               "sage_linear_dinput: bad shape (m=%lld n=%d k=%d)", (long long)m, n, k);
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(dout && w && da, SAGE_EINVAL, "sage_linear_dinput: NULL pointer argument");
+  // C[m][kk] = sum_nn dout[m][nn] * w[nn][kk]: contraction over n, output columns = k
+  GemmArgs g = {};
+  g.seg[0].a = {dout, ld_dout, nullptr, op_vec(dout, ld_dout, n)};
+  g.seg[0].b = {w, ld_w, nullptr, op_vec(w, ld_w, k)};
+  g.seg[0].k = n;
+  g.nseg = 1;
+  g.m = m;
+  g.m_dev = m_dev;
+  g.n = k;
+  g.out = da;
+  g.ld_out = ld_da;
+  g.atomic_out = accumulate ? 1 : 0;
+  return launch_gemm<true, false>(g, 1, stream, "gemm_kernel(dinput)");
+}
+
+extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const float* a,
+                                   sage_i64 ld_a, const sage_i64* rows, sage_i64 m,
+                                   const sage_i64* m_dev, int n, int k, float* dw, sage_i64 ld_dw,
+                                   float* dbias, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && k > 0 && ld_dout >= n && ld_a >= k && ld_dw >= k, SAGE_EINVAL,
+               "sage_linear_dweight: bad shape (m=%lld n=%d k=%d)", (long long)m, n, k);
+  SAGE_REQUIRE(m < (1ll << 31), SAGE_ELIMIT, "sage_linear_dweight: m too large");
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(dout && a && dw, SAGE_EINVAL, "sage_linear_dweight: NULL pointer argument");
+  // C[nn][kk] = sum_mm dout[mm][nn] * a[rows(mm)][kk]: contraction over m
+  GemmArgs g = {};
+  g.seg[0].a = {dout, ld_dout, nullptr, op_vec(dout, ld_dout, n)};
+  g.seg[0].b = {a, ld_a, rows, op_vec(a, ld_a, k)};
+  g.seg[0].k = static_cast<int>(m);
+  g.nseg = 1;
+  g.m = n;
+  g.k_dev = m_dev;
+  g.n = k;
+  g.out = dw;
+  g.ld_out = ld_dw;
+  g.atomic_out = 1;
+  g.colsum = dbias;
+  // split the contraction so that the grid covers the chip about twice
+  const int64_t tiles = cdiv(n, 64) * cdiv(k, k > 64 ? 128 : 64);
+  int64_t splits = cdiv(512, tiles);
+  const int64_t max_splits = cdiv(m, 4 * BK);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
+  splits = cdiv(m, g.k_chunk);
+  return launch_gemm<false, false>(g, static_cast<int>(splits), stream, "gemm_kernel(dweight)");
+}

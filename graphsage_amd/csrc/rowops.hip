@@ -1,0 +1,215 @@
+// Row-wise pieces of the layer and of the training step: L2 normalise (+ReLU) forward and
+// backward, softmax cross-entropy, Adam.  All HBM-bound and tiny next to the gathers
+// (T1 x 256 fp32 = 13.6 MB per pass at Reddit 25/10), so they are plain one-wave-per-row
+// kernels with shuffle reductions.
+//
+//   F.normalize(out, p=2, dim=-1)         reference layers/sage.py:131-132
+//   x.relu_()                             reference models/graphsage.py:47-48
+//   F.cross_entropy(y_hat, y)             reference experiments/fig2a/runners/graphsage_runners.py:43
+//   torch.optim.Adam(...).step()          reference experiments/fig2a/runners/graphsage_runners.py:45,86
+#include "common.h"
+
+namespace sage {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr float kNormEps = 1e-12f;  // torch.nn.functional.normalize default
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__global__ void __launch_bounds__(kBlock)
+l2norm_relu_fwd_kernel(const float* __restrict__ z, int64_t ld_z, int64_t m,
+                       const int64_t* __restrict__ m_dev, int n, float* __restrict__ y,
+                       int64_t ld_y, float* __restrict__ h, int64_t ld_h,
+                       float* __restrict__ inv_norm) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t rows = dev_count(m_dev, m);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (r >= rows) return;
+  const float* zr = z + r * ld_z;
+  float ss = 0.f;
+  for (int f = lane; f < n; f += kWave) {
+    const float v = zr[f];
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), kNormEps);
+  if (lane == 0 && inv_norm != nullptr) inv_norm[r] = 1.f / denom;
+  for (int f = lane; f < n; f += kWave) {
+    const float v = zr[f] / denom;
+    y[r * ld_y + f] = v;
+    if (h != nullptr) h[r * ld_h + f] = v > 0.f ? v : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(kBlock)
+l2norm_relu_bwd_kernel(const float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ y,
+                       int64_t ld_y, const float* __restrict__ inv_norm, int relu_mask, int64_t m,
+                       const int64_t* __restrict__ m_dev, int n, float* __restrict__ dz,
+                       int64_t ld_dz) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t rows = dev_count(m_dev, m);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (r >= rows) return;
+  const float* yr = y + r * ld_y;
+  const float* gr = dh + r * ld_dh;
+  const float inv = inv_norm[r];
+  const bool clamped = inv >= 1.f / kNormEps;  // ||z|| <= eps: the clamp's gradient is zero
+  float dot = 0.f;
+  for (int f = lane; f < n; f += kWave) {
+    const float yv = yr[f];
+    float g = gr[f];
+    if (relu_mask && !(yv > 0.f)) g = 0.f;
+    dot += yv * g;
+  }
+  dot = clamped ? 0.f : wave_sum(dot);
+  for (int f = lane; f < n; f += kWave) {
+    const float yv = yr[f];
+    float g = gr[f];
+    if (relu_mask && !(yv > 0.f)) g = 0.f;
+    dz[r * ld_dz + f] = (g - yv * dot) * inv;
+  }
+}
+
+// One workgroup of 16 waves walks all rows; per-wave partial losses are combined in wave
+// order, so the loss is bitwise reproducible.
+constexpr int kXentBlock = 1024;
+__global__ void __launch_bounds__(kXentBlock)
+softmax_xent_kernel(const float* __restrict__ logits, int64_t ld_logits,
+                    const int64_t* __restrict__ labels, const int64_t* __restrict__ label_rows,
+                    int64_t m, int n, float grad_scale, float* __restrict__ loss,
+                    float* __restrict__ dlogits, int64_t ld_dlogits) {
+  __shared__ float partial[kXentBlock / kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  constexpr int nwaves = kXentBlock / kWave;
+  const float inv_m = 1.f / static_cast<float>(m);
+  float wave_loss = 0.f;
+  for (int64_t r = wave; r < m; r += nwaves) {
+    const float* lr = logits + r * ld_logits;
+    const int64_t lab = labels[label_rows != nullptr ? label_rows[r] : r];
+    float mx = -INFINITY;
+    for (int f = lane; f < n; f += kWave) mx = fmaxf(mx, lr[f]);
+    mx = wave_max(mx);
+    float se = 0.f;
+    for (int f = lane; f < n; f += kWave) se += expf(lr[f] - mx);
+    se = wave_sum(se);
+    const float lse = mx + logf(se);
+    if (lab >= 0 && lab < n) wave_loss += lse - lr[lab];
+    if (dlogits != nullptr) {
+      for (int f = lane; f < n; f += kWave) {
+        float p = expf(lr[f] - lse);
+        if (f == lab) p -= 1.f;
+        dlogits[r * ld_dlogits + f] = p * grad_scale * inv_m;
+      }
+    }
+  }
+  if (lane == 0) partial[wave] = wave_loss;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < nwaves; ++w) s += partial[w];
+    loss[0] = s * inv_m;
+  }
+}
+
+__global__ void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                            float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
+                            int64_t numel, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, float grad_scale,
+                            const int64_t* __restrict__ step_dev) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= numel) return;
+  const float t = static_cast<float>(*step_dev + 1);
+  const float bc1 = 1.f - powf(beta1, t);
+  const float bc2 = 1.f - powf(beta2, t);
+  float g = grad[i] * grad_scale;
+  const float p = param[i];
+  if (weight_decay != 0.f) g += weight_decay * p;
+  const float m1 = beta1 * exp_avg[i] + (1.f - beta1) * g;
+  const float v1 = beta2 * exp_avg_sq[i] + (1.f - beta2) * g * g;
+  exp_avg[i] = m1;
+  exp_avg_sq[i] = v1;
+  const float denom = sqrtf(v1) / sqrtf(bc2) + eps;
+  param[i] = p - (lr / bc1) * (m1 / denom);
+}
+
+__global__ void bump_step_kernel(int64_t* step_dev) { *step_dev += 1; }
+
+}  // namespace
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" int sage_l2norm_relu_fwd(const float* z, sage_i64 ld_z, sage_i64 m,
+                                    const sage_i64* m_dev, int n, float* y, sage_i64 ld_y,
+                                    float* h, sage_i64 ld_h, float* inv_norm, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && ld_z >= n && ld_y >= n && (h == nullptr || ld_h >= n),
+               SAGE_EINVAL, "sage_l2norm_relu_fwd: bad shape");
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(z && y, SAGE_EINVAL, "sage_l2norm_relu_fwd: NULL pointer argument");
+  l2norm_relu_fwd_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+      z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm);
+  SAGE_CHECK_LAUNCH("l2norm_relu_fwd_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_l2norm_relu_bwd(const float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_y,
+                                    const float* inv_norm, int relu_mask, sage_i64 m,
+                                    const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
+                                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && ld_dh >= n && ld_y >= n && ld_dz >= n, SAGE_EINVAL,
+               "sage_l2norm_relu_bwd: bad shape");
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(dh && y && inv_norm && dz, SAGE_EINVAL, "sage_l2norm_relu_bwd: NULL pointer argument");
+  l2norm_relu_bwd_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+      dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz);
+  SAGE_CHECK_LAUNCH("l2norm_relu_bwd_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_softmax_xent(const float* logits, sage_i64 ld_logits, const sage_i64* labels,
+                                 const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
+                                 float* loss, float* dlogits, sage_i64 ld_dlogits, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m > 0 && n > 0 && ld_logits >= n && (dlogits == nullptr || ld_dlogits >= n),
+               SAGE_EINVAL, "sage_softmax_xent: bad shape");
+  SAGE_REQUIRE(n <= 4096, SAGE_ELIMIT, "sage_softmax_xent: n=%d > 4096", n);
+  SAGE_REQUIRE(logits && labels && loss, SAGE_EINVAL, "sage_softmax_xent: NULL pointer argument");
+  softmax_xent_kernel<<<1, kXentBlock, 0, stream>>>(logits, ld_logits, labels, label_rows, m, n,
+                                                    grad_scale, loss, dlogits, ld_dlogits);
+  SAGE_CHECK_LAUNCH("softmax_xent_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                              sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, sage_i64* step_dev,
+                              void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(numel >= 0, SAGE_EINVAL, "sage_adam_step: negative numel");
+  SAGE_REQUIRE(step_dev != nullptr, SAGE_EINVAL, "sage_adam_step: step_dev is NULL");
+  if (numel > 0) {
+    SAGE_REQUIRE(param && grad && exp_avg && exp_avg_sq, SAGE_EINVAL,
+                 "sage_adam_step: NULL pointer argument");
+    adam_kernel<<<static_cast<unsigned>(cdiv(numel, kBlock)), kBlock, 0, stream>>>(
+        param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale,
+        step_dev);
+    SAGE_CHECK_LAUNCH("adam_kernel");
+  }
+  bump_step_kernel<<<1, 1, 0, stream>>>(step_dev);
+  SAGE_CHECK_LAUNCH("bump_step_kernel");
+  return SAGE_OK;
+}

@@ -1,0 +1,467 @@
+"""Tensor-level wrappers over the C ABI (include/sage_hip.h).
+
+Each function validates shapes/dtypes/devices on the host (a wrong shape handed to a
+hand-written kernel is a GPU fault, not an exception), takes raw device pointers from the
+torch tensors and enqueues the kernel on torch's current stream.  torch is plumbing here:
+it owns the memory and the stream, the arithmetic is in libsage_hip.so.
+"""
+import ctypes
+from ctypes import c_void_p
+
+import torch
+
+from . import _lib
+
+REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+EPI_NONE, EPI_BIAS, EPI_RELU = 0, 1, 2
+
+ST_NODES, ST_EDGES, ST_FRONT_BEGIN, ST_FRONT_END, ST_ERROR = 0, 1, 2, 3, 4
+ST_HOP_NODES, ST_HOP_EDGES, STATE_WORDS = 8, 24, 40
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t, dtype, name, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise RuntimeError(f"{name}: tensor required")
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA (HIP) tensor; graphsage_amd has no CPU path")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    return c_void_p(t.data_ptr())
+
+
+def _mat(t, name):
+    """2-D fp32 matrix with unit column stride -> (pointer, row stride)."""
+    if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
+        raise RuntimeError(f"{name}: expected a 2-D tensor with contiguous rows, got "
+                           f"shape {tuple(t.shape)} strides {t.stride()}")
+    ld = t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1))
+    return _p(t, torch.float32, name), int(ld)
+
+
+def _vec(t, dtype, name, min_len=0, allow_none=False):
+    if t is None and allow_none:
+        return None
+    if t.dim() != 1 or not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous 1-D tensor")
+    if t.numel() < min_len:
+        raise RuntimeError(f"{name}: needs at least {min_len} elements, has {t.numel()}")
+    return _p(t, dtype, name)
+
+
+def _count(t, name):
+    """Optional device-side count: a 0-d / 1-element int64 CUDA tensor."""
+    if t is None:
+        return None
+    if t.numel() != 1:
+        raise RuntimeError(f"{name}: device count must have one element")
+    return _p(t, torch.int64, name)
+
+
+# ------------------------------------------------------------------------------- a-1
+def csc_build(edge_index, num_nodes):
+    """to_csc (reference samplers/uniform_loader.py:32) -> (colptr, row, perm)."""
+    lib = _lib.load()
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise RuntimeError("csc_build: edge_index must be [2, E]")
+    edge_index = edge_index.contiguous()
+    E = edge_index.size(1)
+    dev = edge_index.device
+    if E > 0:
+        lo, hi = int(edge_index.min()), int(edge_index.max())
+        if lo < 0 or hi >= num_nodes:
+            raise RuntimeError(f"csc_build: node id out of range [0,{num_nodes}): min {lo} max {hi}")
+    colptr = torch.empty(num_nodes + 1, dtype=torch.int64, device=dev)
+    row = torch.empty(E, dtype=torch.int64, device=dev)
+    perm = torch.empty(E, dtype=torch.int64, device=dev)
+    ws_bytes = lib.sage_csc_build_workspace_bytes(E, num_nodes)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rc = lib.sage_csc_build(_p(edge_index[0], torch.int64, "edge_row"),
+                            _p(edge_index[1], torch.int64, "edge_col"), E, num_nodes,
+                            _p(colptr, torch.int64, "colptr"), _p(row, torch.int64, "row"),
+                            _p(perm, torch.int64, "perm"), c_void_p(ws.data_ptr()), ws_bytes,
+                            _stream())
+    _lib.check(rc, "sage_csc_build")
+    return colptr, row, perm
+
+
+# ------------------------------------------------------------------------------- a-2
+class SampleBuffers:
+    """Caller-owned output/workspace buffers of sage_sample_fanout, reusable across calls."""
+
+    def __init__(self, num_nodes, node_cap, edge_cap, device):
+        lib = _lib.load()
+        self.num_nodes, self.node_cap, self.edge_cap = int(num_nodes), int(node_cap), int(edge_cap)
+        i64 = dict(dtype=torch.int64, device=device)
+        self.node = torch.empty(self.node_cap, **i64)
+        self.src = torch.empty(max(self.edge_cap, 1), **i64)
+        self.dst = torch.empty(max(self.edge_cap, 1), **i64)
+        self.eid = torch.empty(max(self.edge_cap, 1), **i64)
+        self.seg_ptr = torch.empty(self.node_cap + 1, **i64)
+        self.state = torch.zeros(STATE_WORDS, **i64)
+        self.ws_bytes = lib.sage_sample_workspace_bytes(self.node_cap, self.edge_cap)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+
+
+def new_relabel_table(num_nodes, device):
+    """All-ones 64-bit words (see sage_hip.h: relabel_table)."""
+    return torch.full((num_nodes,), -1, dtype=torch.int64, device=device)
+
+
+def sample_fanout(colptr, row, seeds, fanout, rng_seed, rng_counter, table, stamp, buf):
+    """torch_sparse.neighbor_sample (reference samplers/uniform_loader.py:64-72).
+
+    Enqueues the sampler; results land in `buf` (device), sizes in buf.state.  No sync.
+    """
+    lib = _lib.load()
+    num_nodes = colptr.numel() - 1
+    if buf.num_nodes != num_nodes or table.numel() != num_nodes:
+        raise RuntimeError("sample_fanout: buffers/table were sized for another graph")
+    hops = len(fanout)
+    fan = (ctypes.c_int * hops)(*[int(k) for k in fanout])
+    B = seeds.numel()
+    rc = lib.sage_sample_fanout(
+        _vec(colptr, torch.int64, "colptr"), _vec(row, torch.int64, "row"), num_nodes,
+        _vec(seeds, torch.int64, "seeds"), B, fan, hops,
+        int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(rng_counter) & 0xFFFFFFFFFFFFFFFF,
+        _p(table, torch.int64, "relabel_table"), int(stamp), buf.node_cap, buf.edge_cap,
+        _p(buf.node, torch.int64, "node"), _p(buf.src, torch.int64, "src"),
+        _p(buf.dst, torch.int64, "dst"), _p(buf.eid, torch.int64, "eid"),
+        _p(buf.seg_ptr, torch.int64, "seg_ptr"), _p(buf.state, torch.int64, "state"),
+        c_void_p(buf.ws.data_ptr()), buf.ws_bytes, _stream())
+    _lib.check(rc, "sage_sample_fanout")
+
+
+def random_neighbor(colptr, row, start, rng_seed, rng_counter):
+    """torch_cluster.random_walk(..., walk_length=1)[:, 1] (reference samplers/utils.py:22)."""
+    lib = _lib.load()
+    start = start.contiguous()
+    out = torch.empty_like(start)
+    if start.numel() and (int(start.min()) < 0 or int(start.max()) >= colptr.numel() - 1):
+        raise RuntimeError("random_neighbor: start node out of range")
+    rc = lib.sage_random_neighbor(_vec(colptr, torch.int64, "colptr"), _vec(row, torch.int64, "row"),
+                                  _vec(start, torch.int64, "start"), start.numel(),
+                                  int(rng_seed) & 0xFFFFFFFFFFFFFFFF,
+                                  int(rng_counter) & 0xFFFFFFFFFFFFFFFF,
+                                  _p(out, torch.int64, "out"), _stream())
+    _lib.check(rc, "sage_random_neighbor")
+    return out
+
+
+# ------------------------------------------------------------------------------- a-3
+def gather_rows(table, index, num_rows=None, num_rows_dev=None, out=None, checked=False):
+    """out[i] = table[index[i]] for fp32 [N,F] tables and int64 [N] / [N,W] tables
+    (filter_data's index_select, reference samplers/uniform_loader.py:238-239)."""
+    lib = _lib.load()
+    if table.dtype == torch.float32:
+        words = 1
+    elif table.dtype == torch.int64:
+        words = 2
+    else:
+        raise RuntimeError(f"gather_rows: unsupported dtype {table.dtype}")
+    squeeze = table.dim() == 1
+    t2 = table.unsqueeze(1) if squeeze else table
+    if t2.dim() != 2 or (t2.size(1) > 1 and t2.stride(1) != 1) or not t2.is_cuda:
+        raise RuntimeError("gather_rows: table must be a CUDA tensor with contiguous rows")
+    n = index.numel() if num_rows is None else int(num_rows)
+    if n > index.numel():
+        raise RuntimeError("gather_rows: num_rows exceeds len(index)")
+    if not checked and n > 0:
+        lo, hi = int(index[:n].min()), int(index[:n].max())
+        if lo < 0 or hi >= t2.size(0):
+            raise RuntimeError(f"gather_rows: index out of range [0,{t2.size(0)}): min {lo} max {hi}")
+    width = t2.size(1) * words
+    ld_table = (t2.stride(0) if t2.size(0) > 1 else t2.size(1)) * words
+    if out is None:
+        out = torch.empty((n, t2.size(1)), dtype=table.dtype, device=table.device)
+    o2 = out.unsqueeze(1) if out.dim() == 1 else out
+    if o2.size(0) < n or o2.size(1) != t2.size(1) or o2.dtype != table.dtype or \
+            (o2.size(1) > 1 and o2.stride(1) != 1):
+        raise RuntimeError("gather_rows: bad output buffer")
+    ld_out = (o2.stride(0) if o2.size(0) > 1 else o2.size(1)) * words
+    rc = lib.sage_gather_rows(c_void_p(t2.data_ptr()), ld_table, _vec(index, torch.int64, "index"),
+                              n, _count(num_rows_dev, "num_rows_dev"), width,
+                              c_void_p(o2.data_ptr()), ld_out, _stream())
+    _lib.check(rc, "sage_gather_rows")
+    if squeeze and out.dim() == 2:
+        out = out.squeeze(1)
+    return out
+
+
+# ------------------------------------------------------------------------------- a-5
+def gather_reduce_fwd(x, seg_ptr, src, num_targets, reduce, node_map=None,
+                      num_targets_dev=None, out=None, want_argmax=None):
+    """scatter(x[src], dst, reduce) over target segments, fused
+    (reference layers/sage.py:136-137 + :209-210).  Returns (out, argmax or None)."""
+    lib = _lib.load()
+    xp, ld_x = _mat(x, "x")
+    F = x.size(1)
+    T = int(num_targets)
+    if seg_ptr.numel() < T + 1:
+        raise RuntimeError("gather_reduce_fwd: seg_ptr shorter than num_targets+1")
+    if out is None:
+        out = torch.empty((T, F), dtype=torch.float32, device=x.device)
+    op, ld_out = _mat(out, "out")
+    if out.size(0) < T or out.size(1) != F:
+        raise RuntimeError("gather_reduce_fwd: bad output buffer")
+    red = REDUCE[reduce]
+    if want_argmax is None:
+        want_argmax = red == 2
+    argmax = None
+    if red == 2 and want_argmax:
+        argmax = torch.empty((T, F), dtype=torch.int64, device=x.device)
+    rc = lib.sage_gather_reduce_fwd(xp, ld_x, _vec(node_map, torch.int64, "node_map", allow_none=True),
+                                    _vec(seg_ptr, torch.int64, "seg_ptr"),
+                                    _vec(src, torch.int64, "src"), T,
+                                    _count(num_targets_dev, "num_targets_dev"), F, red, op, ld_out,
+                                    _p(argmax, torch.int64, "argmax", allow_none=True), _stream())
+    _lib.check(rc, "sage_gather_reduce_fwd")
+    return out, argmax
+
+
+def gather_reduce_bwd(dout, seg_ptr, src, num_targets, reduce, dx, argmax=None,
+                      num_targets_dev=None):
+    """Accumulates the gradient of gather_reduce_fwd w.r.t. x into dx (pre-initialised)."""
+    lib = _lib.load()
+    dp, ld_dout = _mat(dout, "dout")
+    xp, ld_dx = _mat(dx, "dx")
+    F = dout.size(1)
+    T = int(num_targets)
+    if dx.size(1) != F or dout.size(0) < T or seg_ptr.numel() < T + 1:
+        raise RuntimeError("gather_reduce_bwd: shape mismatch")
+    red = REDUCE[reduce]
+    if red == 2 and (argmax is None or argmax.shape != (T, F) or not argmax.is_contiguous()):
+        raise RuntimeError("gather_reduce_bwd: max needs the forward's argmax [T,F]")
+    rc = lib.sage_gather_reduce_bwd(dp, ld_dout, _vec(seg_ptr, torch.int64, "seg_ptr"),
+                                    _vec(src, torch.int64, "src"),
+                                    _p(argmax, torch.int64, "argmax", allow_none=True), T,
+                                    _count(num_targets_dev, "num_targets_dev"), F, red, xp, ld_dx,
+                                    _stream())
+    _lib.check(rc, "sage_gather_reduce_bwd")
+    return dx
+
+
+def coo_to_csr(edge_src, edge_dst, num_targets):
+    """Stable sort of an arbitrary edge list by target -> (seg_ptr, src_sorted, perm)."""
+    lib = _lib.load()
+    edge_src = edge_src.contiguous()
+    edge_dst = edge_dst.contiguous()
+    E = edge_src.numel()
+    T = int(num_targets)
+    dev = edge_src.device
+    if E > 0:
+        lo, hi = int(edge_dst.min()), int(edge_dst.max())
+        if lo < 0 or hi >= T:
+            raise RuntimeError(f"coo_to_csr: target id out of range [0,{T}): min {lo} max {hi}")
+    seg_ptr = torch.empty(T + 1, dtype=torch.int64, device=dev)
+    src_sorted = torch.empty(E, dtype=torch.int64, device=dev)
+    perm = torch.empty(E, dtype=torch.int64, device=dev)
+    ws_bytes = lib.sage_coo_to_csr_workspace_bytes(E, T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rc = lib.sage_coo_to_csr(_vec(edge_src, torch.int64, "edge_src"),
+                             _vec(edge_dst, torch.int64, "edge_dst"), E, T,
+                             _p(seg_ptr, torch.int64, "seg_ptr"),
+                             _p(src_sorted, torch.int64, "src_sorted"),
+                             _p(perm, torch.int64, "perm"), c_void_p(ws.data_ptr()), ws_bytes,
+                             _stream())
+    _lib.check(rc, "sage_coo_to_csr")
+    return seg_ptr, src_sorted, perm
+
+
+# ------------------------------------------------------------------------------- a-4
+def _rows(t, m, name):
+    if t is None:
+        return None
+    if t.numel() < m:
+        raise RuntimeError(f"{name}: row map shorter than m")
+    return _vec(t, torch.int64, name)
+
+
+def linear_concat_fwd(a1, w1, a2=None, w2=None, bias=None, relu=False, m=None, m_dev=None,
+                      rows1=None, rows2=None, out=None):
+    """out = a1[rows1] @ w1^T + a2[rows2] @ w2^T (+bias)(relu)
+    (reference layers/sage.py:124-129; pool Linear :76,:202)."""
+    lib = _lib.load()
+    a1p, ld_a1 = _mat(a1, "a1")
+    w1p, ld_w1 = _mat(w1, "w1")
+    n, k1 = w1.shape
+    if a1.size(1) != k1:
+        raise RuntimeError("linear_concat_fwd: a1/w1 inner dimensions differ")
+    if m is None:
+        m = rows1.numel() if rows1 is not None else a1.size(0)
+    m = int(m)
+    if rows1 is None and a1.size(0) < m:
+        raise RuntimeError("linear_concat_fwd: a1 has fewer than m rows")
+    k2 = 0
+    a2p = w2p = None
+    ld_a2 = ld_w2 = 0
+    if a2 is not None:
+        a2p, ld_a2 = _mat(a2, "a2")
+        w2p, ld_w2 = _mat(w2, "w2")
+        k2 = w2.size(1)
+        if a2.size(1) != k2 or w2.size(0) != n:
+            raise RuntimeError("linear_concat_fwd: a2/w2 shape mismatch")
+        if rows2 is None and a2.size(0) < m:
+            raise RuntimeError("linear_concat_fwd: a2 has fewer than m rows")
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a1.device)
+    op, ld_out = _mat(out, "out")
+    if out.size(0) < m or out.size(1) != n:
+        raise RuntimeError("linear_concat_fwd: bad output buffer")
+    epi = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0)
+    if bias is not None and bias.numel() != n:
+        raise RuntimeError("linear_concat_fwd: bias length != n")
+    rc = lib.sage_linear_concat_fwd(a1p, ld_a1, _rows(rows1, m, "rows1"), k1, w1p, ld_w1,
+                                    a2p, ld_a2, _rows(rows2, m, "rows2"), k2, w2p, ld_w2,
+                                    _vec(bias, torch.float32, "bias", allow_none=True), epi, m,
+                                    _count(m_dev, "m_dev"), n, op, ld_out, _stream())
+    _lib.check(rc, "sage_linear_concat_fwd")
+    return out
+
+
+def linear_dinput(dout, w, m=None, m_dev=None, out=None, accumulate=False):
+    """da = dout @ w  (w is [n, k])."""
+    lib = _lib.load()
+    dp, ld_dout = _mat(dout, "dout")
+    wp, ld_w = _mat(w, "w")
+    n, k = w.shape
+    m = dout.size(0) if m is None else int(m)
+    if dout.size(1) != n or dout.size(0) < m:
+        raise RuntimeError("linear_dinput: shape mismatch")
+    if out is None:
+        if accumulate:
+            raise RuntimeError("linear_dinput: accumulate needs an output buffer")
+        out = torch.empty((m, k), dtype=torch.float32, device=dout.device)
+    op, ld_da = _mat(out, "da")
+    if out.size(0) < m or out.size(1) != k:
+        raise RuntimeError("linear_dinput: bad output buffer")
+    rc = lib.sage_linear_dinput(dp, ld_dout, wp, ld_w, m, _count(m_dev, "m_dev"), n, k, op, ld_da,
+                                1 if accumulate else 0, _stream())
+    _lib.check(rc, "sage_linear_dinput")
+    return out
+
+
+def linear_dweight(dout, a, m=None, m_dev=None, rows=None, dw=None, dbias=None):
+    """dw += dout^T @ a[rows]  (dw is [n, k]; zero-initialised if not given)."""
+    lib = _lib.load()
+    dp, ld_dout = _mat(dout, "dout")
+    ap, ld_a = _mat(a, "a")
+    n, k = dout.size(1), a.size(1)
+    if m is None:
+        m = rows.numel() if rows is not None else dout.size(0)
+    m = int(m)
+    if dout.size(0) < m or (rows is None and a.size(0) < m):
+        raise RuntimeError("linear_dweight: fewer than m rows")
+    if dw is None:
+        dw = torch.zeros((n, k), dtype=torch.float32, device=dout.device)
+    wp, ld_dw = _mat(dw, "dw")
+    if dw.shape != (n, k):
+        raise RuntimeError("linear_dweight: bad dw buffer")
+    if dbias is not None and dbias.numel() != n:
+        raise RuntimeError("linear_dweight: dbias length != n")
+    rc = lib.sage_linear_dweight(dp, ld_dout, ap, ld_a, _rows(rows, m, "rows"), m,
+                                 _count(m_dev, "m_dev"), n, k, wp, ld_dw,
+                                 _vec(dbias, torch.float32, "dbias", allow_none=True), _stream())
+    _lib.check(rc, "sage_linear_dweight")
+    return dw
+
+
+# ------------------------------------------------------------------------------- rows
+def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None):
+    """y = normalize(z); h = relu(y) if relu (reference layers/sage.py:131-132,
+    models/graphsage.py:47-48).  Returns (y, h or None, inv_norm)."""
+    lib = _lib.load()
+    zp, ld_z = _mat(z, "z")
+    m = z.size(0) if m is None else int(m)
+    n = z.size(1)
+    if y is None:
+        y = torch.empty((m, n), dtype=torch.float32, device=z.device)
+    if relu and h is None:
+        h = torch.empty((m, n), dtype=torch.float32, device=z.device)
+    if inv_norm is None:
+        inv_norm = torch.empty(m, dtype=torch.float32, device=z.device)
+    yp, ld_y = _mat(y, "y")
+    hp, ld_h = (None, 0)
+    if relu:
+        hp, ld_h = _mat(h, "h")
+        if h.size(0) < m or h.size(1) != n:
+            raise RuntimeError("l2norm_relu_fwd: bad h buffer")
+    if z.size(0) < m or y.size(0) < m or y.size(1) != n or inv_norm.numel() < m:
+        raise RuntimeError("l2norm_relu_fwd: bad buffers")
+    rc = lib.sage_l2norm_relu_fwd(zp, ld_z, m, _count(m_dev, "m_dev"), n, yp, ld_y, hp, ld_h,
+                                  _vec(inv_norm, torch.float32, "inv_norm"), _stream())
+    _lib.check(rc, "sage_l2norm_relu_fwd")
+    return y, (h if relu else None), inv_norm
+
+
+def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None):
+    lib = _lib.load()
+    dp, ld_dh = _mat(dh, "dh")
+    yp, ld_y = _mat(y, "y")
+    m = y.size(0) if m is None else int(m)
+    n = y.size(1)
+    if dz is None:
+        dz = torch.empty((m, n), dtype=torch.float32, device=y.device)
+    zp, ld_dz = _mat(dz, "dz")
+    if dh.size(0) < m or dh.size(1) != n or dz.size(0) < m or dz.size(1) != n or \
+            inv_norm.numel() < m or y.size(0) < m:
+        raise RuntimeError("l2norm_relu_bwd: bad buffers")
+    rc = lib.sage_l2norm_relu_bwd(dp, ld_dh, yp, ld_y, _vec(inv_norm, torch.float32, "inv_norm"),
+                                  1 if relu else 0, m, _count(m_dev, "m_dev"), n, zp, ld_dz,
+                                  _stream())
+    _lib.check(rc, "sage_l2norm_relu_bwd")
+    return dz
+
+
+def softmax_xent(logits, labels, label_rows=None, m=None, grad_scale=1.0, loss=None,
+                 dlogits=None, want_grad=True, checked=False):
+    """Mean cross-entropy + gradient (reference fig2a/runners/graphsage_runners.py:43)."""
+    lib = _lib.load()
+    lp, ld = _mat(logits, "logits")
+    m = logits.size(0) if m is None else int(m)
+    n = logits.size(1)
+    if logits.size(0) < m or m <= 0:
+        raise RuntimeError("softmax_xent: bad m")
+    if label_rows is not None:
+        if label_rows.numel() < m:
+            raise RuntimeError("softmax_xent: label_rows shorter than m")
+        if not checked and (int(label_rows[:m].min()) < 0 or int(label_rows[:m].max()) >= labels.numel()):
+            raise RuntimeError("softmax_xent: label_rows out of range")
+    elif labels.numel() < m:
+        raise RuntimeError("softmax_xent: labels shorter than m")
+    if loss is None:
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    if want_grad and dlogits is None:
+        dlogits = torch.empty((m, n), dtype=torch.float32, device=logits.device)
+    gp, ld_g = (None, 0)
+    if dlogits is not None:
+        gp, ld_g = _mat(dlogits, "dlogits")
+        if dlogits.size(0) < m or dlogits.size(1) != n:
+            raise RuntimeError("softmax_xent: bad dlogits buffer")
+    rc = lib.sage_softmax_xent(lp, ld, _vec(labels, torch.int64, "labels"),
+                               _vec(label_rows, torch.int64, "label_rows", allow_none=True), m, n,
+                               float(grad_scale), _p(loss, torch.float32, "loss"), gp, ld_g,
+                               _stream())
+    _lib.check(rc, "sage_softmax_xent")
+    return loss, dlogits
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8,
+              weight_decay=0.0, grad_scale=1.0):
+    """torch.optim.Adam step on flat fp32 buffers; step_dev (int64[1]) is advanced on device."""
+    lib = _lib.load()
+    n = param.numel()
+    for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+        if t.numel() != n or not t.is_contiguous():
+            raise RuntimeError(f"adam_step: {name} must be contiguous with {n} elements")
+    rc = lib.sage_adam_step(_p(param, torch.float32, "param"), _p(grad, torch.float32, "grad"),
+                            _p(exp_avg, torch.float32, "exp_avg"),
+                            _p(exp_avg_sq, torch.float32, "exp_avg_sq"), n, float(lr), float(beta1),
+                            float(beta2), float(eps), float(weight_decay), float(grad_scale),
+                            _count(step_dev, "step_dev"), _stream())
+    _lib.check(rc, "sage_adam_step")

@@ -1,0 +1,249 @@
+/*
+ * sage_hip.h — C ABI of libsage_hip.so, the MI355X (gfx950) implementation of
+ * GraphSAGE's sampled-neighbourhood mini-batch hot path.
+ *
+ * Every entry point replaces one third-party native call made by the reference
+ * (wilcoln/graphsage); the call site it replaces is cited as  <file>:<line>  relative to
+ * the reference tree.  The reference binds those natives through PyTorch custom ops
+ * (torch.ops.torch_sparse.*, torch_scatter.scatter, torch_geometric Linear); a maintainer
+ * binds this library through ctypes exactly as graphsage_amd/_lib.py does (see
+ * INTEGRATION.md).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (hipMalloc'ed / torch CUDA tensors) unless the
+ *     parameter name ends in `_host`.
+ *   - Index tensors are int64 (`sage_i64`), as in the reference's torch.LongTensor
+ *     (samplers/uniform_loader.py:60-61).  Features/weights/gradients are IEEE fp32.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued on it; no entry point synchronises, allocates or frees device memory or
+ *     retains a pointer after it returns, so every call may be captured in a HIP graph.
+ *   - Return value 0 = success; otherwise a negative SAGE_E* code and a message in
+ *     sage_last_error() (thread-local).  The Python binding raises RuntimeError, the
+ *     convention of the natives it replaces (TORCH_CHECK).
+ *   - `*_dev` count arguments are optional device pointers to a row/edge count that is
+ *     only known on the device (a sampled batch's size).  When non-NULL the kernels read
+ *     the count from device memory and the host-side count is the launch upper bound.
+ */
+#ifndef SAGE_HIP_H
+#define SAGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t sage_i64;
+
+#define SAGE_OK 0
+#define SAGE_EINVAL (-1)    /* bad argument (shape, alignment, NULL pointer)          */
+#define SAGE_EWORKSPACE (-2) /* workspace too small                                     */
+#define SAGE_ELAUNCH (-3)   /* HIP runtime reported an error at launch                 */
+#define SAGE_ELIMIT (-4)    /* size beyond a documented limit of this library          */
+
+/* reduce ops of sage_gather_reduce_* — the `reduce` strings of
+ * layers/sage.py:195-210 ('mean' | 'max' | 'sum'; 'gcn'/'mean_pool' map to mean,
+ * 'max_pool' to max). */
+#define SAGE_REDUCE_SUM 0
+#define SAGE_REDUCE_MEAN 1
+#define SAGE_REDUCE_MAX 2
+
+/* epilogue flags of sage_linear_concat_fwd */
+#define SAGE_EPI_NONE 0
+#define SAGE_EPI_BIAS 1 /* + bias[n]            (pool Linear, layers/sage.py:76)       */
+#define SAGE_EPI_RELU 2 /* relu                 (layers/sage.py:202,206)               */
+
+/* words of the sampler's device state block (sage_i64 state[SAGE_STATE_WORDS]) */
+#define SAGE_ST_NODES 0      /* number of sampled nodes so far  (len(samples))           */
+#define SAGE_ST_EDGES 1      /* number of sampled edges so far                           */
+#define SAGE_ST_FRONT_BEGIN 2 /* local id range of the nodes the next hop expands       */
+#define SAGE_ST_FRONT_END 3
+#define SAGE_ST_ERROR 4      /* bit0: node capacity exceeded, bit1: edge capacity        */
+#define SAGE_ST_HOP_NODES 8  /* [8+h]  = #nodes after hop h (h=0: the seeds)             */
+#define SAGE_ST_HOP_EDGES 24 /* [24+h] = #edges after hop h (h=0: 0)                     */
+#define SAGE_STATE_WORDS 40
+#define SAGE_MAX_HOPS 15
+
+const char* sage_last_error(void);
+int sage_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * (a-1) CSC build.  Replaces torch_geometric.loader.utils.to_csc(data, device='cpu')
+ * called at samplers/uniform_loader.py:32:
+ *     perm = argsort(col * N + row);  row_out = row[perm];  colptr = ind2ptr(col[perm], N)
+ * Stable sort: equal (col,row) pairs keep their input order in `perm`.
+ * Limits: N*N must fit in 63 bits.
+ * ---------------------------------------------------------------------------------- */
+size_t sage_csc_build_workspace_bytes(sage_i64 num_edges, sage_i64 num_nodes);
+int sage_csc_build(const sage_i64* edge_row, const sage_i64* edge_col, sage_i64 num_edges,
+                   sage_i64 num_nodes, sage_i64* colptr /*[N+1]*/, sage_i64* row_out /*[E]*/,
+                   sage_i64* perm /*[E]*/, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-2) Multi-hop uniform fan-out neighbour sampling without replacement.  Replaces
+ *     torch.ops.torch_sparse.neighbor_sample(colptr, row, index, num_neighbors,
+ *                                            replace=False, directed=True)
+ * called at samplers/uniform_loader.py:64-72.  Outputs follow that op:
+ *     node[0:n_nodes]  global ids in first-seen order, node[0:B] == seeds
+ *     src[e] (the op's `row`) local id of the sampled neighbour,
+ *     dst[e] (the op's `col`) local id of the target, eid[e] offset into `row`
+ * and in addition seg_ptr[0:node_cap+1]: edges whose target is local node t are
+ * [seg_ptr[t], seg_ptr[t+1]) — the op emits edges grouped by target in frontier order,
+ * so this CSR comes for free and is what the aggregation kernels consume.
+ *
+ * Randomness: Philox4x32-10, key = (rng_seed lo, rng_seed hi + hop),
+ * counter = (draw>>2, local id of target, rng_counter lo, rng_counter hi); draw t of a
+ * target with deg > k picks r = mulhi32(word[t&3], j+1), j = deg-k+t (Robert Floyd),
+ * r replaced by j if r was already chosen.  Bit-exact against oracle/sampler.py for the
+ * same (rng_seed, rng_counter); the upstream op's CPU generator stream cannot be
+ * reproduced on any device, so equivalence to it is distributional.
+ *
+ * relabel_table: sage_u64[num_nodes] scratch owned by the caller, initialised ONCE to
+ * all-ones bytes (0xFF); `stamp` must be > 0 and larger than in any earlier call that
+ * used the same table (stale entries are recognised by their stamp, no clearing pass).
+ * Concurrent calls must not share a table.
+ * state: sage_i64[SAGE_STATE_WORDS], written by the call (see SAGE_ST_*).
+ * Capacity overflow truncates the output and sets SAGE_ST_ERROR; with all fan-outs >= 0,
+ * node_cap = B*(1 + k1 + k1*k2 + ...) and edge_cap = B*(k1 + k1*k2 + ...) never overflow.
+ * Limits: 0 < hops <= SAGE_MAX_HOPS, fan-out <= 2048 (or < 0 = all neighbours),
+ * edge_cap < 2^31.
+ * ---------------------------------------------------------------------------------- */
+size_t sage_sample_workspace_bytes(sage_i64 node_cap, sage_i64 edge_cap);
+int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, sage_i64 num_nodes,
+                       const sage_i64* seeds, int num_seeds, const int* fanout_host, int hops,
+                       uint64_t rng_seed, uint64_t rng_counter, uint64_t* relabel_table,
+                       uint32_t stamp, sage_i64 node_cap, sage_i64 edge_cap,
+                       sage_i64* node /*[node_cap]*/, sage_i64* src /*[edge_cap]*/,
+                       sage_i64* dst /*[edge_cap]*/, sage_i64* eid /*[edge_cap]*/,
+                       sage_i64* seg_ptr /*[node_cap+1]*/, sage_i64* state, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
+/* (f-2) one uniform random in-neighbour per start node; replaces
+ * torch_cluster.random_walk(row, col, start, walk_length=1)[:,1] at samplers/utils.py:22.
+ * A start with no neighbour returns itself (torch_cluster's behaviour).  Philox key =
+ * (rng_seed), counter = (i>>2, 0x52570000, rng_counter lo, hi). */
+int sage_random_neighbor(const sage_i64* colptr, const sage_i64* row, const sage_i64* start,
+                         sage_i64 num_start, uint64_t rng_seed, uint64_t rng_counter,
+                         sage_i64* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-3) Row gather.  Replaces torch_geometric.loader.utils.filter_data's
+ * index_select of node-level attributes (samplers/uniform_loader.py:238-239):
+ *     out[i, 0:width] = table[index[i], 0:width]     (rows of `width` 32-bit words)
+ * `ld_table`/`ld_out` are row strides in 32-bit words.  Serves fp32 features
+ * (width = F) and int64 labels / ids (width = 2).
+ * ---------------------------------------------------------------------------------- */
+int sage_gather_rows(const void* table, sage_i64 ld_table, const sage_i64* index,
+                     sage_i64 num_rows, const sage_i64* num_rows_dev, int width, void* out,
+                     sage_i64 ld_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-5) Fused gather + segment reduce.  Replaces SAGE.message (x_j = x[edge_index[0]],
+ * layers/sage.py:136-137) followed by torch_scatter.scatter(x_j, edge_index[1], dim=-2,
+ * dim_size, reduce) at layers/sage.py:209-210, without materialising x_j:
+ *     out[t, :] = reduce_{e in [seg_ptr[t], seg_ptr[t+1])} X[row_of(src[e]), :]
+ * row_of(s) = node_map ? node_map[s] : s   (node_map = the batch's `node` vector, so the
+ * gather reads the global feature table directly instead of a materialised batch.x).
+ * Empty segments give 0 for all three reduces; mean divides by max(count,1).
+ * max also writes argmax[t, f] = the edge index e that supplied the maximum (first such
+ * edge in segment order on ties), or -1 for an empty segment; argmax may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int sage_gather_reduce_fwd(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                           const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                           const sage_i64* num_targets_dev, int num_features, int reduce,
+                           float* out, sage_i64 ld_out, sage_i64* argmax, void* stream);
+
+/* Backward of the above w.r.t. x (autograd of scatter + index_select):
+ *   sum : dx[src[e], :] += dout[t, :]            mean: += dout[t, :] / max(count_t, 1)
+ *   max : dx[src[argmax[t,f]], f] += dout[t, f]  (argmax >= 0)
+ * dx must be pre-initialised (zero, or a gradient to accumulate into); adds are fp32
+ * atomics, so the summation order — not the set of addends — may vary between runs. */
+int sage_gather_reduce_bwd(const float* dout, sage_i64 ld_dout, const sage_i64* seg_ptr,
+                           const sage_i64* src, const sage_i64* argmax, sage_i64 num_targets,
+                           const sage_i64* num_targets_dev, int num_features, int reduce,
+                           float* dx, sage_i64 ld_dx, void* stream);
+
+/* COO -> target-CSR for an arbitrary edge_index (any order): stable counting sort of the
+ * edges by target.  Needed because SAGE.forward accepts any [2,E] tensor
+ * (layers/sage.py:99-100) while the kernels above want segments.  perm[i] = input edge
+ * placed at sorted position i, src_sorted[i] = edge_src[perm[i]]. */
+size_t sage_coo_to_csr_workspace_bytes(sage_i64 num_edges, sage_i64 num_targets);
+int sage_coo_to_csr(const sage_i64* edge_src, const sage_i64* edge_dst, sage_i64 num_edges,
+                    sage_i64 num_targets, sage_i64* seg_ptr /*[T+1]*/,
+                    sage_i64* src_sorted /*[E]*/, sage_i64* perm /*[E]*/, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * (a-4) self||neighbour Linear.  Replaces lin_l(out) + lin_r(x_r) of
+ * layers/sage.py:124-129 (two bias-free torch_geometric Linear, :78-81) and the pool
+ * Linear (+bias, +ReLU) of layers/sage.py:76,202,206:
+ *     out[m, n] = sum_k a1[r1(m), k] * w1[n, k]  +  sum_k a2[r2(m), k] * w2[n, k]
+ *                 (+ bias[n]) (relu)
+ * r1/r2: optional row maps (NULL = identity) so the root term can be read straight from
+ * the global feature table through the batch's `node` vector.  a2/w2 may be NULL
+ * (k2 = 0: 'gcn' aggregator / root_weight=False / pool).  Exact fp32 arithmetic on the
+ * matrix cores (v_mfma_f32_32x32x2_f32): each output is an fp32 fma chain over k.
+ * Alignment: every pointer and row stride must be a multiple of 8 bytes.
+ * ---------------------------------------------------------------------------------- */
+int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sage_i64* rows1, int k1,
+                           const float* w1, sage_i64 ld_w1, const float* a2, sage_i64 ld_a2,
+                           const sage_i64* rows2, int k2, const float* w2, sage_i64 ld_w2,
+                           const float* bias, int epilogue, sage_i64 m,
+                           const sage_i64* m_dev, int n, float* out, sage_i64 ld_out,
+                           void* stream);
+
+/* Input gradient:  da[m, k] = sum_n dout[m, n] * w[n, k]   (da = dout @ w), optionally
+ * accumulated into da (beta = 1) instead of overwriting it (beta = 0). */
+int sage_linear_dinput(const float* dout, sage_i64 ld_dout, const float* w, sage_i64 ld_w,
+                       sage_i64 m, const sage_i64* m_dev, int n, int k, float* da,
+                       sage_i64 ld_da, int accumulate, void* stream);
+
+/* Weight gradient: dw[n, k] = sum_m dout[m, n] * a[r(m), k]  (dw = dout^T @ a), split
+ * over m across workgroups and combined with fp32 atomics into dw, which must be
+ * pre-initialised (zero, or a gradient to accumulate into).  dbias[n] = sum_m dout[m,n]
+ * if dbias != NULL. */
+int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const float* a, sage_i64 ld_a,
+                        const sage_i64* rows, sage_i64 m, const sage_i64* m_dev, int n, int k,
+                        float* dw, sage_i64 ld_dw, float* dbias, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Row-wise epilogues of the layer and the loss.
+ * ---------------------------------------------------------------------------------- */
+/* y = z / max(||z||_2, 1e-12)  (F.normalize(p=2, dim=-1), layers/sage.py:131-132) and,
+ * if h != NULL, h = relu(y) (the in-place x.relu_() of models/graphsage.py:47-48).
+ * inv_norm[m] = 1 / max(||z||, eps) is kept for the backward.  y may alias z. */
+int sage_l2norm_relu_fwd(const float* z, sage_i64 ld_z, sage_i64 m, const sage_i64* m_dev,
+                         int n, float* y, sage_i64 ld_y, float* h, sage_i64 ld_h,
+                         float* inv_norm, void* stream);
+/* dz = (g - y * <y, g>) * inv_norm, with g = relu_mask ? dh * [y > 0] : dh.
+ * Rows whose norm was clamped by eps (inv_norm == 1e12) get dz = g * inv_norm, the
+ * gradient torch's clamp_min gives.  dz may alias dh. */
+int sage_l2norm_relu_bwd(const float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_y,
+                         const float* inv_norm, int relu_mask, sage_i64 m,
+                         const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
+                         void* stream);
+
+/* Mean softmax cross-entropy over m rows and its gradient (F.cross_entropy of
+ * experiments/fig2a/runners/graphsage_runners.py:43 / nn.CrossEntropyLoss of
+ * trainers/node_level_graphsage_trainers.py:41).  labels are gathered through
+ * label_rows (NULL = identity): label of row i = labels[label_rows[i]].
+ * loss[0] = mean_i( logsumexp(logits[i]) - logits[i, label_i] );
+ * dlogits = (softmax - onehot) * grad_scale / m.  loss is overwritten (one workgroup
+ * reduces deterministically).  Limit: n <= 4096. */
+int sage_softmax_xent(const float* logits, sage_i64 ld_logits, const sage_i64* labels,
+                      const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
+                      float* loss, float* dlogits, sage_i64 ld_dlogits, void* stream);
+
+/* Adam (torch.optim.Adam defaults semantics, no amsgrad, L2 weight_decay added to the
+ * gradient) on one flat parameter buffer.  step_dev: device int64 step counter,
+ * incremented by the kernel (so a captured graph advances it on replay). */
+int sage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                   sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float grad_scale, sage_i64* step_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGE_HIP_H */

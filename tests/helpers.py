@@ -1,0 +1,44 @@
+"""Shared test inputs (seeded, small enough for the CPU oracle to finish in seconds)."""
+import numpy as np
+import torch
+
+
+def random_graph(num_nodes, num_edges, seed, isolated=0, hubs=0):
+    """Directed edge list [2,E] with optional nodes of in-degree 0 and a few hubs."""
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, num_nodes, num_edges)
+    dst = rng.integers(isolated, num_nodes, num_edges)  # nodes < isolated get no in-edges
+    if hubs:
+        hub_ids = rng.integers(isolated, num_nodes, hubs)
+        extra = num_edges // 4
+        src = np.concatenate([src, rng.integers(0, num_nodes, extra)])
+        dst = np.concatenate([dst, hub_ids[rng.integers(0, hubs, extra)]])
+    return np.stack([src, dst]).astype(np.int64)
+
+
+def make_layers(dims, aggregator, seed):
+    """Random layer parameters in the oracle's dict form; dims = [in, hidden, ..., out]."""
+    g = torch.Generator().manual_seed(seed)
+    layers = []
+    for fin, fout in zip(dims[:-1], dims[1:]):
+        p = {"lin_l": torch.randn(fout, fin, generator=g) / fin ** 0.5}
+        if aggregator != "gcn":
+            p["lin_r"] = torch.randn(fout, fin, generator=g) / fin ** 0.5
+        if aggregator in ("max_pool", "mean_pool"):
+            p["pool_w"] = torch.randn(fin, fin, generator=g) / fin ** 0.5
+            p["pool_b"] = torch.randn(fin, generator=g) * 0.1
+        layers.append(p)
+    return layers
+
+
+def load_layers(model, layers):
+    """Copy oracle-form parameters into a graphsage_amd GraphSAGE / list of SAGE layers."""
+    mods = model.layers if hasattr(model, "layers") else model
+    with torch.no_grad():
+        for m, p in zip(mods, layers):
+            m.lin_l.weight.copy_(p["lin_l"])
+            if "lin_r" in p:
+                m.lin_r.weight.copy_(p["lin_r"])
+            if "pool_w" in p:
+                m.pool.weight.copy_(p["pool_w"])
+                m.pool.bias.copy_(p["pool_b"])
