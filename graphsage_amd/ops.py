@@ -44,6 +44,9 @@ def _mat(t, name):
     return _p(t, torch.float32, name), int(ld)
 
 
+_dummies = {}
+
+
 def _vec(t, dtype, name, min_len=0, allow_none=False):
     if t is None and allow_none:
         return None
@@ -51,6 +54,14 @@ def _vec(t, dtype, name, min_len=0, allow_none=False):
         raise RuntimeError(f"{name}: expected a contiguous 1-D tensor")
     if t.numel() < min_len:
         raise RuntimeError(f"{name}: needs at least {min_len} elements, has {t.numel()}")
+    if t.numel() == 0:
+        # an empty tensor has a NULL data pointer, which the C ABI rejects as "missing":
+        # hand it a valid (never dereferenced) address instead
+        _p(t, dtype, name)
+        key = (t.device, dtype)
+        if key not in _dummies:
+            _dummies[key] = torch.zeros(8, dtype=dtype, device=t.device)
+        return c_void_p(_dummies[key].data_ptr())
     return _p(t, dtype, name)
 
 

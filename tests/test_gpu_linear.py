@@ -1,0 +1,128 @@
+"""GPU parity: the MFMA self||neighbour Linear (forward, d-input, d-weight) and the row-wise
+kernels, against fp32 torch on the CPU.  Tolerance: the kernel is an exact-fp32 fma chain, so
+it differs from a CPU fp32 GEMM only by summation order: |err| <= ~1e-6 * sum|a*b|; with
+K <= 1433 unit-variance terms that is rtol 1e-4 / atol 1e-4 (stated, not tuned)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import sage_ref
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 1e-4
+
+
+def _rand(shape, g, scale=1.0):
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("m,n,k1,k2", [(1000, 256, 602, 602), (512, 41, 256, 256), (70, 7, 1433, 1433),
+                                       (333, 121, 50, 50), (64, 64, 32, 0), (1, 5, 3, 3),
+                                       (200, 130, 77, 0), (129, 256, 256, 256)])
+def test_linear_concat_fwd(dev, m, n, k1, k2):
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m + n)
+    a1, w1 = _rand((m, k1), g), _rand((n, k1), g, k1 ** -0.5)
+    want = a1 @ w1.t()
+    a2 = w2 = None
+    if k2:
+        a2, w2 = _rand((m, k2), g), _rand((n, k2), g, k2 ** -0.5)
+        want = want + a2 @ w2.t()
+    out = ops.linear_concat_fwd(a1.to(dev), w1.to(dev), a2.to(dev) if k2 else None,
+                                w2.to(dev) if k2 else None)
+    torch.testing.assert_close(out.cpu(), want, rtol=RTOL, atol=ATOL)
+
+
+def test_linear_concat_rowmaps_bias_relu_devcount(dev):
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(0)
+    N, m, n, k = 900, 300, 96, 602
+    table = _rand((N, k), g)
+    ld = (k + 15) // 16 * 16
+    tpad = torch.full((N, ld), float("nan"), device=dev)
+    tpad[:, :k] = table.to(dev)
+    tview = tpad[:, :k]
+    rows = torch.randperm(N, generator=g)[:m]
+    agg = _rand((m, k), g)
+    w1, w2, b = _rand((n, k), g, k ** -0.5), _rand((n, k), g, k ** -0.5), _rand((n,), g)
+    want = F.relu(agg @ w1.t() + table[rows] @ w2.t() + b)
+    out = ops.linear_concat_fwd(agg.to(dev), w1.to(dev), tview, w2.to(dev), bias=b.to(dev), relu=True,
+                                rows2=rows.to(dev), m=m)
+    torch.testing.assert_close(out.cpu(), want, rtol=RTOL, atol=ATOL)
+    # device-side row count: rows >= 100 untouched
+    buf = torch.full((m, n), -3.0, device=dev)
+    ops.linear_concat_fwd(agg.to(dev), w1.to(dev), tview, w2.to(dev), bias=b.to(dev), relu=True,
+                          rows2=rows.to(dev), m=m, m_dev=torch.tensor([100], device=dev), out=buf)
+    torch.testing.assert_close(buf[:100].cpu(), want[:100], rtol=RTOL, atol=ATOL)
+    assert bool((buf[100:] == -3.0).all())
+
+
+@pytest.mark.parametrize("m,n,k", [(1000, 256, 602), (512, 41, 256), (77, 7, 1433), (300, 121, 50), (5, 3, 2)])
+def test_linear_backward(dev, m, n, k):
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(k)
+    dout, w, a = _rand((m, n), g), _rand((n, k), g, k ** -0.5), _rand((m, k), g)
+    da = ops.linear_dinput(dout.to(dev), w.to(dev))
+    torch.testing.assert_close(da.cpu(), dout @ w, rtol=RTOL, atol=ATOL)
+    # accumulate into an existing gradient
+    base = _rand((m, k), g)
+    acc = base.to(dev).clone()
+    ops.linear_dinput(dout.to(dev), w.to(dev), out=acc, accumulate=True)
+    torch.testing.assert_close(acc.cpu(), base + dout @ w, rtol=RTOL, atol=ATOL)
+    dbias = torch.zeros(n, device=dev)
+    dw = ops.linear_dweight(dout.to(dev), a.to(dev), dbias=dbias)
+    torch.testing.assert_close(dw.cpu(), dout.t() @ a, rtol=RTOL, atol=2e-4 * max(1.0, (m / 100) ** 0.5))
+    torch.testing.assert_close(dbias.cpu(), dout.sum(0), rtol=RTOL, atol=1e-4 * max(1.0, (m / 100) ** 0.5))
+    # row-mapped operand + device-side contraction length
+    rows = torch.randint(0, m, (m,), generator=g)
+    mdev = torch.tensor([max(m // 2, 1)], device=dev)
+    dw2 = ops.linear_dweight(dout.to(dev), a.to(dev), rows=rows.to(dev), m_dev=mdev)
+    h = max(m // 2, 1)
+    torch.testing.assert_close(dw2.cpu(), dout[:h].t() @ a[rows[:h]], rtol=RTOL,
+                               atol=2e-4 * max(1.0, (m / 100) ** 0.5))
+
+
+@pytest.mark.parametrize("m,n", [(1000, 256), (512, 41), (3, 7), (100, 1000)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_l2norm_relu(dev, m, n, relu):
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(n)
+    z = _rand((m, n), g)
+    z[0] = 0.0                                           # a zero row: clamp by eps, output 0
+    zt = z.clone().requires_grad_(True)
+    y = F.normalize(zt, p=2.0, dim=-1)
+    h = y.relu() if relu else y
+    yk, hk, inv = ops.l2norm_relu_fwd(z.to(dev), relu)
+    torch.testing.assert_close(yk.cpu(), y.detach(), rtol=1e-5, atol=1e-6)
+    if relu:
+        torch.testing.assert_close(hk.cpu(), h.detach(), rtol=1e-5, atol=1e-6)
+    dh = _rand((m, n), g)
+    h.backward(dh)
+    dz = ops.l2norm_relu_bwd(dh.to(dev), yk, inv, relu)
+    torch.testing.assert_close(dz[1:].cpu(), zt.grad[1:], rtol=1e-4, atol=1e-5)
+
+
+def test_softmax_xent_and_adam(dev):
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(0)
+    m, n, N = 512, 41, 3000
+    logits = _rand((m, n), g)
+    labels = torch.randint(0, n, (N,), generator=g)
+    rows = torch.randint(0, N, (m,), generator=g)
+    lt = logits.clone().requires_grad_(True)
+    loss = F.cross_entropy(lt, labels[rows])
+    loss.backward()
+    lk, gk = ops.softmax_xent(logits.to(dev), labels.to(dev), label_rows=rows.to(dev))
+    torch.testing.assert_close(lk.cpu()[0], loss.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gk.cpu(), lt.grad, rtol=1e-4, atol=1e-7)
+    # Adam against the oracle's restatement of torch.optim.Adam
+    p = _rand((5000,), g)
+    pk, mk, vk = p.to(dev).clone(), torch.zeros(5000, device=dev), torch.zeros(5000, device=dev)
+    pr, mr, vr = p.clone(), torch.zeros(5000), torch.zeros(5000)
+    step = torch.zeros(1, dtype=torch.int64, device=dev)
+    for t in range(1, 4):
+        grad = _rand((5000,), g)
+        ops.adam_step(pk, grad.to(dev), mk, vk, step, 1e-3, weight_decay=0.01)
+        pr, mr, vr = sage_ref.adam_ref(pr, grad, mr, vr, t, 1e-3, weight_decay=0.01)
+        torch.testing.assert_close(pk.cpu(), pr, rtol=1e-5, atol=1e-6)
+    assert int(step) == 3

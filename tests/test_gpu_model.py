@@ -1,0 +1,129 @@
+"""GPU parity: SAGE layer, GraphSAGE model (pruned and unpruned), loader batches and one
+training step, against the CPU oracle.  fp32 tolerances: layer outputs are L2-normalised
+(|y| <= 1), differences come from summation order in the reduce and the GEMM: atol 2e-5;
+gradients rtol 1e-3 / atol 2e-5 (aggregator mean rtol 1e-5/atol 1e-6 is tested on
+the kernel itself in test_gpu_gather.py)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import csc, sage_ref, sampler
+from tests.helpers import load_layers, make_layers, random_graph
+
+pytestmark = pytest.mark.gpu
+ATOL = 2e-5
+
+
+@pytest.mark.parametrize("aggregator", ["mean", "max", "sum", "gcn", "max_pool", "mean_pool"])
+def test_sage_layer_forward_backward(dev, aggregator):
+    from graphsage_amd.layers import SAGE
+    n, e, fin, fout = 400, 5000, 50, 24
+    ei = torch.from_numpy(random_graph(n, e, seed=3, isolated=7))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, fin, generator=g)
+    p = make_layers([fin, fout], aggregator, 1)[0]
+    layer = SAGE(fin, fout, aggregator).to(dev)
+    load_layers([layer], [p])
+    xr = x.clone().requires_grad_(True)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    want = sage_ref.sage_forward(xr, ei, pr["lin_l"], pr.get("lin_r"), aggregator, pr.get("pool_w"), pr.get("pool_b"))
+    xd = x.to(dev).requires_grad_(True)
+    out = layer(xd, ei.to(dev))
+    torch.testing.assert_close(out.cpu(), want.detach(), rtol=1e-4, atol=ATOL)
+    dout = torch.randn(n, fout, generator=g)
+    want.backward(dout)
+    out.backward(dout.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=ATOL)
+    torch.testing.assert_close(layer.lin_l.weight.grad.cpu(), pr["lin_l"].grad, rtol=1e-3, atol=1e-4)
+    if "lin_r" in pr:
+        torch.testing.assert_close(layer.lin_r.weight.grad.cpu(), pr["lin_r"].grad, rtol=1e-3, atol=1e-4)
+    if "pool_w" in pr:
+        torch.testing.assert_close(layer.pool.weight.grad.cpu(), pr["pool_w"].grad, rtol=1e-3, atol=1e-4)
+        torch.testing.assert_close(layer.pool.bias.grad.cpu(), pr["pool_b"].grad, rtol=1e-3, atol=1e-4)
+
+
+def test_sage_layer_api_details(dev):
+    from graphsage_amd.layers import SAGE
+    layer = SAGE(8, 4, 'mean').to(dev)
+    assert set(layer.state_dict()) == {"lin_l.weight", "lin_r.weight"}
+    assert set(SAGE(8, 4, 'gcn').state_dict()) == {"lin_l.weight"}
+    assert set(SAGE(8, 4, 'max_pool').state_dict()) == {"lin_l.weight", "lin_r.weight", "pool.weight", "pool.bias"}
+    x = torch.randn(5, 8, device=dev)
+    ei = torch.tensor([[0, 1], [1, 2]], device=dev)
+    out = layer(x, ei, None)                  # third positional arg tolerated (size / edge_weight)
+    assert out.shape == (5, 4)
+    torch.testing.assert_close(out.norm(dim=1), torch.ones(5, device=dev), rtol=1e-5, atol=1e-5)
+    empty = layer(x, torch.zeros((2, 0), dtype=torch.int64, device=dev))
+    torch.testing.assert_close(empty, F.normalize(x @ layer.lin_r.weight.t(), dim=-1), rtol=1e-4, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        layer(x.cpu(), ei.cpu())              # no CPU fallback
+    with pytest.raises(AssertionError):
+        SAGE(8, 4, 'median')
+
+
+def _cora_like(seed=0):
+    from graphsage_amd.datasets import planted_partition
+    d = planted_partition(600, 4000, 33, 5, seed=seed)
+    d.train_mask = torch.zeros(600, dtype=torch.bool)
+    d.train_mask[torch.randperm(600, generator=torch.Generator().manual_seed(seed))[:150]] = True
+    return d
+
+
+@pytest.mark.parametrize("aggregator", ["mean", "max_pool", "gcn"])
+def test_loader_and_model_match_oracle(dev, aggregator):
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    data = _cora_like()
+    loader = UniformLoader(data, num_neighbors=[5, 3], input_nodes=data.train_mask, batch_size=64,
+                           shuffle=False, num_workers=4, persistent_workers=False, seed=11)
+    assert len(loader) == 3 and len(loader.dataset) == 150
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), 600)
+    layers = make_layers([33, 16, 5], aggregator, 2)
+    model = GraphSAGE(33, 16, aggregator, 2, 5).to(dev)
+    load_layers(model, layers)
+    seeds_all = data.train_mask.nonzero().view(-1)
+    for b, batch in enumerate(loader):
+        seeds = seeds_all[b * 64:(b + 1) * 64].numpy()
+        node, src, dst, eid, hop_nodes, hop_edges = sampler.neighbor_sample(c0, r0, seeds, [5, 3], 11, b)
+        assert batch.batch_size == len(seeds)
+        assert batch.n_id.cpu().numpy().tolist() == node.tolist()
+        assert batch.edge_index.cpu().numpy().tolist() == [src.tolist(), dst.tolist()]
+        assert torch.equal(batch.x.cpu(), data.x[node])
+        assert torch.equal(batch.y.cpu(), data.y[node])
+        want = sage_ref.graphsage_forward(data.x[node], torch.from_numpy(np.stack([src, dst])), layers, aggregator)
+        batch = batch.to(dev)
+        got = model(batch.x, batch.edge_index)[:batch.batch_size]
+        torch.testing.assert_close(got.cpu(), want[:len(seeds)], rtol=1e-4, atol=ATOL)
+        got_fb = model.forward_batch(batch)
+        torch.testing.assert_close(got_fb.cpu(), want[:len(seeds)], rtol=1e-4, atol=ATOL)
+        model.prune_to_seeds = False
+        full = model(batch.x, batch.edge_index)
+        assert full.shape[0] == len(node)
+        torch.testing.assert_close(full.cpu(), want, rtol=1e-4, atol=ATOL)
+        model.prune_to_seeds = True
+
+
+def test_train_step_gradients_match_oracle(dev):
+    """fig2a's step: forward over the sampled batch, CE on the seed rows, backward."""
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    data = _cora_like(1)
+    loader = UniformLoader(data, num_neighbors=[6, 4], input_nodes=data.train_mask, batch_size=50, seed=3)
+    layers = make_layers([33, 16, 5], "mean", 4)
+    model = GraphSAGE(33, 16, "mean", 2, 5).to(dev)
+    load_layers(model, layers)
+    batch = next(iter(loader))
+    node, ei = batch.n_id.cpu(), batch.edge_index.cpu()
+    ref_layers = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
+    loss_ref, _ = sage_ref.train_step_loss(data.x, data.y, node, ei[0], ei[1], 50, ref_layers)
+    loss_ref.backward()
+    for variant in ("tensor", "batch"):
+        model.zero_grad()
+        y_hat = model.forward_batch(batch) if variant == "batch" else model(batch.x, batch.edge_index)[:50]
+        loss = F.cross_entropy(y_hat, batch.y[:50])
+        loss.backward()
+        torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-5, atol=1e-6)
+        for m, p in zip(model.layers, ref_layers):
+            torch.testing.assert_close(m.lin_l.weight.grad.cpu(), p["lin_l"].grad, rtol=1e-3, atol=1e-5)
+            torch.testing.assert_close(m.lin_r.weight.grad.cpu(), p["lin_r"].grad, rtol=1e-3, atol=1e-5)
