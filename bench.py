@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py — Reddit-shaped GraphSAGE-mean 25/10 training step throughput on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched
+one rank per GPU by torch.distributed.run.  Prints ONE JSON line on rank 0.
+
+A step is fig2a's (reference experiments/fig2a/runners/graphsage_runners.py:38-46): sample
+(25,10) -> gather -> 2-layer GraphSAGE-mean forward -> cross-entropy on the 512 seed rows ->
+backward -> Adam; every rank does its own 512 seeds per step (weak scaling), gradients are
+all-reduced over RCCL.  Inputs (graph, features, labels, weights) are resident in HBM before
+the timed region.  `roofline` is for the dominant HBM-bound kernel, the layer-0 fused
+gather+mean (see DESIGN.md for the byte formula); `cpu_baseline` times the oracle's CPU
+restatement of the same step (rank 0, N = 1 only) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+SHAPES = {
+    # name: (num_nodes, num_edges, num_features, num_classes, num_train)
+    "reddit": (232965, 114615892, 602, 41, 153431),
+    "reddit-small": (23296, 4000000, 602, 41, 15343),   # for quick functional runs only
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="reddit", choices=sorted(SHAPES))
+    ap.add_argument("--batch-size", type=int, default=512)
+    ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--fanout", type=int, nargs="+", default=[25, 10])
+    ap.add_argument("--aggregator", default="mean")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
+    return ap.parse_args()
+
+
+def cpu_baseline(data_cpu, colptr, row, seeds_list, fanout, layers, steps, lr):
+    """The oracle's restatement of the reference step, as written (unfused, all sampled rows
+    through both layers), on the host cores.  Returns (seeds/s, cores, description)."""
+    import numpy as np
+    import torch.nn.functional as F
+
+    from oracle import sage_ref, sampler, sampler_c
+    cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(cores)
+    x, y = data_cpu
+    params = []
+    ref_layers = []
+    for p in layers:
+        d = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ref_layers.append(d)
+        params += list(d.values())
+    opt = torch.optim.Adam(params, lr=lr)
+    samp = sampler_c.neighbor_sample if sampler_c.available() else sampler.neighbor_sample
+    times = []
+    for i, seeds in enumerate(seeds_list[: steps + 1]):
+        t0 = time.perf_counter()
+        node, src, dst, eid, _, _ = samp(colptr, row, seeds, fanout, 0, i)
+        opt.zero_grad()
+        loss, _ = sage_ref.train_step_loss(x, y, torch.from_numpy(np.asarray(node)), torch.from_numpy(np.asarray(src)),
+                                           torch.from_numpy(np.asarray(dst)), len(seeds), ref_layers)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    timed = times[1:] if len(times) > 1 else times          # first step = warm-up
+    per_step = sum(timed) / len(timed)
+    return len(seeds_list[0]) / per_step, cores, per_step, len(timed)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (graphsage_amd has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=dev)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    from graphsage_amd import ops
+    from graphsage_amd.datasets import reddit_like_device
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+
+    N, E, Fdim, C, n_train = SHAPES[args.workload]
+    B, K = args.batch_size, list(args.fanout)
+    t_setup = time.perf_counter()
+    data = reddit_like_device(N, E, Fdim, C, seed=0, device=dev)   # identical on every rank
+    graph = device_graph(data)
+    feats, labels = graph.features(data), graph.labels(data)
+    data.edge_index = None                                          # CSC is resident; free the COO
+    torch.cuda.empty_cache()
+    torch.manual_seed(0)
+    model = GraphSAGE(Fdim, args.hidden, args.aggregator, len(K), C).to(dev)
+    init_layers = [{"lin_l": m.lin_l.weight.detach().cpu().clone(), "lin_r": m.lin_r.weight.detach().cpu().clone()}
+                   for m in model.layers]
+    sampler = NeighborSampler.from_graph(graph, K, seed=0)   # the CSC is already resident
+    pg = torch.distributed.group.WORLD if world > 1 else None
+    engine = SageTrainEngine(model, sampler, feats, labels, B, lr=args.lr, world_size=world, process_group=pg)
+
+    # seeds: first n_train ids of randperm(N, seed 0); rank r takes the strided shard r::world
+    gen = torch.Generator().manual_seed(0)
+    train = torch.randperm(N, generator=gen)[:n_train]
+    mine = train[rank::world].to(dev)
+    n_batches = mine.numel() // B
+    if n_batches == 0:
+        raise SystemExit("workload too small for this batch size / world size")
+
+    def seeds_of(step):
+        b = step % n_batches
+        return mine[b * B:(b + 1) * B]
+
+    def counter_of(step):
+        return step * world + rank
+
+    total = args.warmup + args.steps
+    states = torch.zeros((args.steps, ops.STATE_WORDS), dtype=torch.int64, device=dev)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    probe = not args.no_probe
+
+    # the engine's forward_backward with the layer-0 gather bracketed by events
+    orig_gather = ops.gather_reduce_fwd
+    cur = {"i": -1}
+
+    def probed_gather(x, *a, **kw):
+        if cur["i"] >= 0 and kw.get("node_map") is not None:
+            ev[cur["i"]][0].record()
+            out = orig_gather(x, *a, **kw)
+            ev[cur["i"]][1].record()
+            return out
+        return orig_gather(x, *a, **kw)
+
+    if probe:
+        ops.gather_reduce_fwd = probed_gather
+
+    for s in range(args.warmup):
+        engine.step(seeds_of(s), counter_of(s))
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    setup_s = time.perf_counter() - t_setup
+    t0 = time.perf_counter()
+    for s in range(args.warmup, total):
+        cur["i"] = s - args.warmup
+        engine.step(seeds_of(s), counter_of(s))
+        states[s - args.warmup].copy_(engine.buf.state, non_blocking=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    cur["i"] = -1
+    ops.gather_reduce_fwd = orig_gather
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+
+    st = states.cpu()
+    if int(st[:, ops.ST_ERROR].max()) != 0:
+        raise SystemExit("sampler reported an error during the timed region")
+    loss = float(engine.loss)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        roofline = None
+        if probe:
+            # layer-0 fused gather+mean: algorithmic bytes per launch from the ACTUAL counts
+            e_b = st[:, ops.ST_EDGES].double()
+            t1 = st[:, ops.ST_HOP_NODES + 1].double()
+            ld = feats.stride(0)
+            bytes_per = 4.0 * Fdim * e_b + 4.0 * Fdim * t1 + 8.0 * (2 * e_b + t1 + 1)
+            ms = torch.tensor([a.elapsed_time(b) for a, b in ev], dtype=torch.float64)
+            achieved = float(bytes_per.sum() / (ms.sum() * 1e-3) / 1e9)
+            roofline = {"bound": "hbm", "kernel": "gather_reduce_fwd_kernel (layer 0, mean, node_map)",
+                        "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
+                        "algorithmic_bytes_per_launch": int(bytes_per.mean()), "row_stride_floats": int(ld)}
+        cpu = None
+        if world == 1 and args.cpu_steps > 0:
+            x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
+            colptr, row = graph.colptr.cpu().numpy(), graph.row.cpu().numpy()
+            seeds_list = [train[i * B:(i + 1) * B].numpy() for i in range(args.cpu_steps + 1)]
+            v, cores, per_step, n_timed = cpu_baseline((x_cpu, y_cpu), colptr, row, seeds_list, K, init_layers,
+                                                       args.cpu_steps, args.lr)
+            cpu = {"value": round(v, 1), "unit": "seed nodes/s", "cores": cores, "kind": "port",
+                   "sample": f"{n_timed} timed steps (+1 warm-up) of the same workload, B={B}, "
+                             f"{per_step:.2f} s/step, oracle restatement of the reference step as written"}
+        out = {
+            "metric": "Reddit GraphSAGE-mean 25/10 fwd+bwd seed nodes/s; gather GB/s vs HBM peak",
+            "value": round(value, 1), "unit": "seed nodes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shaped synthetic: N={N} E={E} F={Fdim} C={C}, "
+                                   f"B={B}/GPU, fan-out {K}, hidden {args.hidden}, aggregator {args.aggregator}, "
+                                   f"Adam lr {args.lr}, fig2a step (supervised term only)",
+                       "parallelism": f"dp{world}", "global_batch": world * B},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "final_loss": round(loss, 5), "setup_s": round(setup_s, 1),
+            "avg_nodes_per_batch": float(st[:, ops.ST_NODES].double().mean()),
+            "avg_edges_per_batch": float(st[:, ops.ST_EDGES].double().mean()),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,91 +58,116 @@ struct GemmArgs {
 // ---- global -> register staging of one operand tile ---------------------------------
 // KC  (contraction dim contiguous in memory): tile = MN rows x BK cols, row index = m/n.
 // !KC (m/n contiguous in memory):             tile = BK rows x MN cols, row index = k.
-template <bool KC, int MN>
-struct TileRegs {
-  float v[MN * BK / kThreads];
-};
+// Everything about the thread -> (row, col) mapping is compile-time, and nothing consumes a
+// loaded value before store(): the loads of K-step s+1 stay in flight while the MFMAs of
+// step s run.  Row-map lookups never sit in front of a data load on the critical path: for KC
+// operands the mapped row pointers are fixed for the whole segment (begin()), for !KC
+// operands the row ids of step s+1 are fetched while step s is being loaded.
+template <int VEC> struct VecT;
+template <> struct VecT<4> { using type = float4; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<1> { using type = float; };
 
 template <bool KC, int MN, int VEC>
-__device__ inline void load_tile(TileRegs<KC, MN>& r, const Operand& op, int64_t mn0,
-                                 int64_t mn_lim, int k0, int k_lim) {
-  constexpr int UNITS = MN * BK / VEC;  // vector units in the tile
-  constexpr int PASSES = UNITS / kThreads;
-  constexpr int UPR = (KC ? BK : MN) / VEC;  // units per tile row
+struct TileLoader {
+  static constexpr int UNITS = MN * BK / VEC;
+  static constexpr int PASSES = UNITS / kThreads;
+  static constexpr int UPR = (KC ? BK : MN) / VEC;  // vector units per tile row
+  static_assert(PASSES >= 1, "tile too small for the thread block");
+  using VT = typename VecT<VEC>::type;
+
+  VT v[PASSES];
+  const float* rowp[PASSES];  // KC: row base pointers (nullptr = row beyond the limit)
+  int64_t rows[PASSES];       // !KC: (mapped) row ids of the K-step issued next
+  Operand op;
+  int64_t mn0, mn_lim;
+  int k_end;
+
+  __device__ inline int trow(int p) const { return (threadIdx.x + p * kThreads) / UPR; }
+  __device__ inline int tcol(int p) const { return ((threadIdx.x + p * kThreads) % UPR) * VEC; }
+
+  __device__ inline void begin(const Operand& o, int64_t mn0_, int64_t mn_lim_, int k_beg, int k_end_) {
+    op = o; mn0 = mn0_; mn_lim = mn_lim_; k_end = k_end_;
+    // all row-map lookups are issued back to back (clamped indices, no branch between them)
+    int64_t ids[PASSES];
 #pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    const int u = threadIdx.x + p * kThreads;
-    const int trow = u / UPR;
-    const int tcol = (u % UPR) * VEC;
-    // global coordinates of the first element of this unit
-    const int64_t grow = KC ? (mn0 + trow) : static_cast<int64_t>(k0 + trow);
-    const int64_t gcol = KC ? static_cast<int64_t>(k0 + tcol) : (mn0 + tcol);
-    const int64_t row_lim = KC ? mn_lim : static_cast<int64_t>(k_lim);
-    const int64_t col_lim = KC ? static_cast<int64_t>(k_lim) : mn_lim;
-    float tmp[VEC];
+    for (int p = 0; p < PASSES; ++p) {
+      const int64_t r = KC ? (mn0 + trow(p)) : (static_cast<int64_t>(k_beg) + trow(p));
+      const int64_t lim = KC ? mn_lim : static_cast<int64_t>(k_end);
+      ids[p] = r < lim ? r : lim - 1;
+    }
+    if (op.rowmap != nullptr) {
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) tmp[j] = 0.f;
-    if (grow < row_lim && gcol < col_lim) {
-      const int64_t mrow = op.rowmap != nullptr ? op.rowmap[grow] : grow;
-      const float* src = op.p + mrow * op.ld + gcol;
-      if constexpr (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(src);
-        tmp[0] = t.x; tmp[1] = t.y; tmp[2] = t.z; tmp[3] = t.w;
-      } else if constexpr (VEC == 2) {
-        const float2 t = *reinterpret_cast<const float2*>(src);
-        tmp[0] = t.x; tmp[1] = t.y;
+      for (int p = 0; p < PASSES; ++p) ids[p] = op.rowmap[ids[p]];
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      if (KC) {
+        rowp[p] = (mn0 + trow(p) < mn_lim) ? op.p + ids[p] * op.ld : nullptr;
       } else {
-        tmp[0] = *src;
+        rows[p] = ids[p];
       }
-      // a ragged last vector may read row padding: zero what lies beyond the limit
+    }
+  }
+
+  // request the tile whose first contraction index is k0
+  __device__ inline void issue(int k0) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const float* src = nullptr;
+      if (KC) {
+        if (rowp[p] != nullptr && k0 + tcol(p) < k_end) src = rowp[p] + k0 + tcol(p);
+      } else {
+        if (k0 + trow(p) < k_end && mn0 + tcol(p) < mn_lim) src = op.p + rows[p] * op.ld + mn0 + tcol(p);
+      }
+      if (src != nullptr) {
+        v[p] = *reinterpret_cast<const VT*>(src);
+      } else {
+        v[p] = VT{};
+      }
+    }
+    if (!KC) {
+      // row ids of the NEXT K-step; they arrive while this step's data is in flight
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const int64_t r = static_cast<int64_t>(k0) + BK + trow(p);
+        rows[p] = r < k_end ? r : static_cast<int64_t>(k_end) - 1;
+      }
+      if (op.rowmap != nullptr) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) rows[p] = op.rowmap[rows[p]];
+      }
+    }
+  }
+
+  // write the tile requested by issue(k0) into LDS ([BK][LDS_LD], k-major)
+  template <int LDS_LD>
+  __device__ inline void store(int k0, float* lds) const {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      float e[VEC];
+      if constexpr (VEC == 4) { e[0] = v[p].x; e[1] = v[p].y; e[2] = v[p].z; e[3] = v[p].w; }
+      else if constexpr (VEC == 2) { e[0] = v[p].x; e[1] = v[p].y; }
+      else { e[0] = v[p]; }
+      // a ragged last vector may have read row padding: zero what lies beyond the limit
+      const int64_t c0 = KC ? static_cast<int64_t>(k0 + tcol(p)) : (mn0 + tcol(p));
+      const int64_t c_lim = KC ? static_cast<int64_t>(k_end) : mn_lim;
 #pragma unroll
       for (int j = 1; j < VEC; ++j) {
-        if (gcol + j >= col_lim) tmp[j] = 0.f;
+        if (c0 + j >= c_lim) e[j] = 0.f;
       }
-    }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) r.v[p * VEC + j] = tmp[j];
-  }
-}
-
-template <bool KC, int MN, int VEC, int LDS_LD>
-__device__ inline void store_tile(const TileRegs<KC, MN>& r, float* lds /*[BK][LDS_LD]*/) {
-  constexpr int UNITS = MN * BK / VEC;
-  constexpr int PASSES = UNITS / kThreads;
-  constexpr int UPR = (KC ? BK : MN) / VEC;
-#pragma unroll
-  for (int p = 0; p < PASSES; ++p) {
-    const int u = threadIdx.x + p * kThreads;
-    const int trow = u / UPR;
-    const int tcol = (u % UPR) * VEC;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      if (KC) {
-        lds[(tcol + j) * LDS_LD + trow] = r.v[p * VEC + j];  // transpose: [k][mn]
-      } else {
-        lds[trow * LDS_LD + tcol + j] = r.v[p * VEC + j];
+      for (int j = 0; j < VEC; ++j) {
+        if (KC) lds[(tcol(p) + j) * LDS_LD + trow(p)] = e[j];  // transpose: [k][mn]
+        else lds[trow(p) * LDS_LD + tcol(p) + j] = e[j];
       }
     }
   }
-}
-
-template <bool KC, int MN>
-__device__ inline void load_tile_any(TileRegs<KC, MN>& r, const Operand& op, int64_t mn0,
-                                     int64_t mn_lim, int k0, int k_lim) {
-  if (op.vec == 4) load_tile<KC, MN, 4>(r, op, mn0, mn_lim, k0, k_lim);
-  else if (op.vec == 2) load_tile<KC, MN, 2>(r, op, mn0, mn_lim, k0, k_lim);
-  else load_tile<KC, MN, 1>(r, op, mn0, mn_lim, k0, k_lim);
-}
-template <bool KC, int MN, int LDS_LD>
-__device__ inline void store_tile_any(const TileRegs<KC, MN>& r, int vec, float* lds) {
-  if (vec == 4) store_tile<KC, MN, 4, LDS_LD>(r, lds);
-  else if (vec == 2) store_tile<KC, MN, 2, LDS_LD>(r, lds);
-  else store_tile<KC, MN, 1, LDS_LD>(r, lds);
-}
+};
 
 // 4 waves as 2 (M) x 2 (N); each wave owns (BM/2) x (BN/2) = TM x TN tiles of 32x32.
-template <bool A_KC, bool B_KC, int BM, int BN>
-__global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
+template <bool A_KC, bool B_KC, int BM, int BN, int VEC>
+__global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr int LDA = BM + (A_KC ? 2 : 4);
   constexpr int LDB = BN + (B_KC ? 2 : 4);
@@ -179,8 +204,8 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) csum[i] = 0.f;
 
-  TileRegs<A_KC, BM> ra;
-  TileRegs<B_KC, BN> rb;
+  TileLoader<A_KC, BM, VEC> la;
+  TileLoader<B_KC, BN, VEC> lb;
 
   for (int s = 0; s < g.nseg; ++s) {
     const Segment& sg = g.seg[s];
@@ -197,18 +222,19 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
     if (k_beg >= k_end) continue;
 
     int cur = 0;
-    load_tile_any<A_KC, BM>(ra, sg.a, m0, m_lim, k_beg, k_end);
-    load_tile_any<B_KC, BN>(rb, sg.b, n0, n_lim, k_beg, k_end);
-    __syncthreads();  // previous segment's readers are done with the buffers
-    store_tile_any<A_KC, BM, LDA>(ra, sg.a.vec, As);
-    store_tile_any<B_KC, BN, LDB>(rb, sg.b.vec, Bs);
+    la.begin(sg.a, m0, m_lim, k_beg, k_end);
+    lb.begin(sg.b, n0, n_lim, k_beg, k_end);
+    la.issue(k_beg);
+    lb.issue(k_beg);
+    la.template store<LDA>(k_beg, As);
+    lb.template store<LDB>(k_beg, Bs);
     __syncthreads();
 
     for (int k0 = k_beg; k0 < k_end; k0 += BK) {
       const bool has_next = k0 + BK < k_end;
       if (has_next) {
-        load_tile_any<A_KC, BM>(ra, sg.a, m0, m_lim, k0 + BK, k_end);
-        load_tile_any<B_KC, BN>(rb, sg.b, n0, n_lim, k0 + BK, k_end);
+        la.issue(k0 + BK);
+        lb.issue(k0 + BK);
       }
       const float* as = As + cur * (BK * LDA);
       const float* bs = Bs + cur * (BK * LDB);
@@ -229,8 +255,8 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
         }
       }
       if (has_next) {
-        store_tile_any<A_KC, BM, LDA>(ra, sg.a.vec, As + (cur ^ 1) * (BK * LDA));
-        store_tile_any<B_KC, BN, LDB>(rb, sg.b.vec, Bs + (cur ^ 1) * (BK * LDB));
+        la.template store<LDA>(k0 + BK, As + (cur ^ 1) * (BK * LDA));
+        lb.template store<LDB>(k0 + BK, Bs + (cur ^ 1) * (BK * LDB));
       }
       __syncthreads();
       cur ^= 1;
@@ -238,22 +264,36 @@ __global__ void __launch_bounds__(kThreads) gemm_kernel(GemmArgs g) {
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3)+8*(e>>2)+4*half
+  const bool relu = (g.epilogue & SAGE_EPI_RELU) != 0;
+  float bv[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int64_t col = n0 + wn0 + j * 32 + l31;
+    bv[j] = ((g.epilogue & SAGE_EPI_BIAS) && col < n_lim) ? g.bias[col] : 0.f;
+    // consume the load here so that the stores below do not each wait on vmcnt(0)
+    asm volatile("" : "+v"(bv[j]));
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int64_t col = n0 + wn0 + j * 32 + l31;
-      if (col >= n_lim) continue;
-      const float bv = (g.epilogue & SAGE_EPI_BIAS) ? g.bias[col] : 0.f;
+      const int64_t row0 = m0 + wm0 + i * 32 + 4 * half;
+      float* base = g.out + row0 * g.ld_out + col;
+      if (g.atomic_out) {  // block-uniform
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-        if (row >= m_lim) continue;
-        float v = acc[i][j][e] + bv;
-        if (g.epilogue & SAGE_EPI_RELU) v = v > 0.f ? v : 0.f;
-        float* dst = g.out + row * g.ld_out + col;
-        if (g.atomic_out) atomicAdd(dst, v);
-        else *dst = v;
+        for (int e = 0; e < 16; ++e) {
+          const int r = (e & 3) + 8 * (e >> 2);
+          if (col < n_lim && row0 + r < m_lim) atomicAdd(base + r * g.ld_out, acc[i][j][e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = (e & 3) + 8 * (e >> 2);
+          float v = acc[i][j][e] + bv[j];
+          if (relu) v = fmaxf(v, 0.f);
+          if (col < n_lim && row0 + r < m_lim) base[r * g.ld_out] = v;
+        }
       }
     }
   }
@@ -278,20 +318,33 @@ int op_vec(const float* p, int64_t ld, int64_t width) {
   return 1;
 }
 
-template <bool A_KC, bool B_KC>
-int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream, const char* what) {
-  if (g.m <= 0 || g.n <= 0) return SAGE_OK;
+template <bool A_KC, bool B_KC, int VEC>
+int launch_gemm_vec(const GemmArgs& g, int splits, hipStream_t stream, const char* what) {
   if (g.n > 64) {
     dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)), static_cast<unsigned>(cdiv(g.n, 128)),
               static_cast<unsigned>(splits));
-    gemm_kernel<A_KC, B_KC, 64, 128><<<grid, kThreads, 0, stream>>>(g);
+    gemm_kernel<A_KC, B_KC, 64, 128, VEC><<<grid, kThreads, 0, stream>>>(g);
   } else {
     dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)), static_cast<unsigned>(cdiv(g.n, 64)),
               static_cast<unsigned>(splits));
-    gemm_kernel<A_KC, B_KC, 64, 64><<<grid, kThreads, 0, stream>>>(g);
+    gemm_kernel<A_KC, B_KC, 64, 64, VEC><<<grid, kThreads, 0, stream>>>(g);
   }
   SAGE_CHECK_LAUNCH(what);
   return SAGE_OK;
+}
+
+template <bool A_KC, bool B_KC>
+int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream, const char* what) {
+  if (g.m <= 0 || g.n <= 0) return SAGE_OK;
+  // one vector width for the whole kernel: the narrowest any operand allows
+  int vec = 4;
+  for (int s = 0; s < g.nseg; ++s) {
+    if (g.seg[s].a.vec < vec) vec = g.seg[s].a.vec;
+    if (g.seg[s].b.vec < vec) vec = g.seg[s].b.vec;
+  }
+  if (vec == 4) return launch_gemm_vec<A_KC, B_KC, 4>(g, splits, stream, what);
+  if (vec == 2) return launch_gemm_vec<A_KC, B_KC, 2>(g, splits, stream, what);
+  return launch_gemm_vec<A_KC, B_KC, 1>(g, splits, stream, what);
 }
 
 }  // namespace

@@ -95,22 +95,56 @@ softmax_xent_kernel(const float* __restrict__ logits, int64_t ld_logits,
   constexpr int nwaves = kXentBlock / kWave;
   const float inv_m = 1.f / static_cast<float>(m);
   float wave_loss = 0.f;
-  for (int64_t r = wave; r < m; r += nwaves) {
-    const float* lr = logits + r * ld_logits;
-    const int64_t lab = labels[label_rows != nullptr ? label_rows[r] : r];
-    float mx = -INFINITY;
-    for (int f = lane; f < n; f += kWave) mx = fmaxf(mx, lr[f]);
-    mx = wave_max(mx);
-    float se = 0.f;
-    for (int f = lane; f < n; f += kWave) se += expf(lr[f] - mx);
-    se = wave_sum(se);
-    const float lse = mx + logf(se);
-    if (lab >= 0 && lab < n) wave_loss += lse - lr[lab];
-    if (dlogits != nullptr) {
-      for (int f = lane; f < n; f += kWave) {
-        float p = expf(lr[f] - lse);
-        if (f == lab) p -= 1.f;
-        dlogits[r * ld_dlogits + f] = p * grad_scale * inv_m;
+  if (n <= kWave) {
+    // one logit per lane; R rows per iteration so that R independent load chains
+    // (label_rows -> labels, logits) are in flight at once
+    constexpr int R = 8;
+    for (int64_t r0 = wave; r0 < m; r0 += static_cast<int64_t>(nwaves) * R) {
+      float v[R];
+      int64_t lab[R];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int64_t r = r0 + static_cast<int64_t>(i) * nwaves;
+        const int64_t rc = r < m ? r : m - 1;
+        v[i] = lane < n ? logits[rc * ld_logits + lane] : -INFINITY;
+        lab[i] = label_rows != nullptr ? label_rows[rc] : rc;
+      }
+#pragma unroll
+      for (int i = 0; i < R; ++i) lab[i] = labels[lab[i]];
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int64_t r = r0 + static_cast<int64_t>(i) * nwaves;
+        if (r >= m) break;
+        const float mx = wave_max(v[i]);
+        const float ex = lane < n ? expf(v[i] - mx) : 0.f;
+        const float lse = mx + logf(wave_sum(ex));
+        const float at_label = wave_sum(lane == lab[i] ? v[i] : 0.f);
+        if (lab[i] >= 0 && lab[i] < n) wave_loss += lse - at_label;
+        if (dlogits != nullptr && lane < n) {
+          float p = expf(v[i] - lse);
+          if (lane == lab[i]) p -= 1.f;
+          dlogits[r * ld_dlogits + lane] = p * grad_scale * inv_m;
+        }
+      }
+    }
+  } else {
+    for (int64_t r = wave; r < m; r += nwaves) {
+      const float* lr = logits + r * ld_logits;
+      const int64_t lab = labels[label_rows != nullptr ? label_rows[r] : r];
+      float mx = -INFINITY;
+      for (int f = lane; f < n; f += kWave) mx = fmaxf(mx, lr[f]);
+      mx = wave_max(mx);
+      float se = 0.f;
+      for (int f = lane; f < n; f += kWave) se += expf(lr[f] - mx);
+      se = wave_sum(se);
+      const float lse = mx + logf(se);
+      if (lab >= 0 && lab < n) wave_loss += lse - lr[lab];
+      if (dlogits != nullptr) {
+        for (int f = lane; f < n; f += kWave) {
+          float p = expf(lr[f] - lse);
+          if (f == lab) p -= 1.f;
+          dlogits[r * ld_dlogits + f] = p * grad_scale * inv_m;
+        }
       }
     }
   }

@@ -88,9 +88,21 @@ class NeighborSampler:
             raise NotImplementedError("directed=False is not supported (never used by the reference's scripts)")
         assert isinstance(num_neighbors, (list, tuple))
         self.data_cls = data.__class__
-        self.num_neighbors = [int(k) for k in num_neighbors]
         self.replace, self.directed = replace, directed
-        self.graph = device_graph(data)
+        self._attach(device_graph(data), num_neighbors, seed)
+
+    @classmethod
+    def from_graph(cls, graph, num_neighbors, seed: Optional[int] = None):
+        """Sampler over an already resident DeviceGraph (no edge list needed any more)."""
+        self = cls.__new__(cls)
+        self.data_cls = Data
+        self.replace, self.directed = False, True
+        self._attach(graph, num_neighbors, seed)
+        return self
+
+    def _attach(self, graph, num_neighbors, seed):
+        self.num_neighbors = [int(k) for k in num_neighbors]
+        self.graph = graph
         self.colptr, self.row, self.perm = self.graph.colptr, self.graph.row, self.graph.perm
         self.seed = settings.SEED if seed is None else int(seed)
         self.counter = 0          # advances once per sampled batch
