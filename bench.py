@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-baseline steps (0 = skip)")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of HIP-graph replay")
     return ap.parse_args()
 
 
@@ -135,53 +136,61 @@ def main():
     def counter_of(step):
         return step * world + rank
 
-    total = args.warmup + args.steps
-    states = torch.zeros((args.steps, ops.STATE_WORDS), dtype=torch.int64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     probe = not args.no_probe
+    use_graph = not args.no_graph
+    cur = {"i": 0}
 
-    # the engine's forward_backward with the layer-0 gather bracketed by events
-    orig_gather = ops.gather_reduce_fwd
-    cur = {"i": -1}
+    if use_graph:
+        # HIP-graph replay: batch b = seeds mine[b*B:(b+1)*B], Philox counter rank + b*world
+        engine.capture(mine, counter0=rank, counter_stride=world, split_gather=probe)
+        before = (lambda: ev[cur["i"]][0].record()) if probe else None
+        after = (lambda: ev[cur["i"]][1].record()) if probe else None
 
-    def probed_gather(x, *a, **kw):
-        if cur["i"] >= 0 and kw.get("node_map") is not None:
-            ev[cur["i"]][0].record()
-            out = orig_gather(x, *a, **kw)
-            ev[cur["i"]][1].record()
-            return out
-        return orig_gather(x, *a, **kw)
-
-    if probe:
-        ops.gather_reduce_fwd = probed_gather
+        def run_step(s, timed):
+            if timed:
+                engine.replay(before, after)
+            else:
+                engine.replay()
+    else:
+        def run_step(s, timed):
+            engine.sample(seeds_of(s), counter_of(s))
+            engine.state_sum.add_(engine.buf.state)
+            if probe and timed:
+                ev[cur["i"]][0].record()
+                engine.gather_layer0()
+                ev[cur["i"]][1].record()
+            else:
+                engine.gather_layer0()
+            engine.forward_backward(skip_gather0=True)
+            engine.all_reduce()
+            engine.optimizer_step()
 
     for s in range(args.warmup):
-        engine.step(seeds_of(s), counter_of(s))
+        run_step(s, False)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
+    st0 = engine.state_sum.clone()
     setup_s = time.perf_counter() - t_setup
     t0 = time.perf_counter()
-    for s in range(args.warmup, total):
+    for s in range(args.warmup, args.warmup + args.steps):
         cur["i"] = s - args.warmup
-        engine.step(seeds_of(s), counter_of(s))
-        states[s - args.warmup].copy_(engine.buf.state, non_blocking=True)
+        run_step(s, True)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    cur["i"] = -1
-    ops.gather_reduce_fwd = orig_gather
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
 
-    st = states.cpu()
-    if int(st[:, ops.ST_ERROR].max()) != 0:
-        raise SystemExit("sampler reported an error during the timed region")
+    st = (engine.state_sum - st0).cpu().double()       # sums over the timed steps
+    if int(engine.state_sum[ops.ST_ERROR]) != 0:
+        raise SystemExit("sampler reported an error during the run")
     loss = float(engine.loss)
 
     if rank == 0:
@@ -190,17 +199,25 @@ def main():
         roofline = None
         if probe:
             # layer-0 fused gather+mean: algorithmic bytes per launch from the ACTUAL counts
-            e_b = st[:, ops.ST_EDGES].double()
-            t1 = st[:, ops.ST_HOP_NODES + 1].double()
+            e_b = float(st[ops.ST_EDGES])                    # summed over the timed launches
+            t1 = float(st[ops.ST_HOP_NODES + 1])
             ld = feats.stride(0)
-            bytes_per = 4.0 * Fdim * e_b + 4.0 * Fdim * t1 + 8.0 * (2 * e_b + t1 + 1)
+            bytes_sum = 4.0 * Fdim * e_b + 4.0 * Fdim * t1 + 8.0 * (2 * e_b + t1 + args.steps)
             ms = torch.tensor([a.elapsed_time(b) for a, b in ev], dtype=torch.float64)
-            achieved = float(bytes_per.sum() / (ms.sum() * 1e-3) / 1e9)
+            achieved = float(bytes_sum / (float(ms.sum()) * 1e-3) / 1e9)
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "gather_traffic.json")
+            if args.workload == "reddit" and os.path.exists(tpath):
+                # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and
+                # WRITE_SIZE in separate runs, gfx950 correction applied) — measured offline, see file
+                with open(tpath) as f:
+                    tj = json.load(f)
+                traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/gather_traffic.json"
             roofline = {"bound": "hbm", "kernel": "gather_reduce_fwd_kernel (layer 0, mean, node_map)",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
-                        "algorithmic_bytes_per_launch": int(bytes_per.mean()), "row_stride_floats": int(ld)}
+                        "algorithmic_bytes_per_launch": int(bytes_sum / args.steps), "row_stride_floats": int(ld)}
         cpu = None
         if world == 1 and args.cpu_steps > 0:
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
@@ -222,8 +239,9 @@ def main():
                        "parallelism": f"dp{world}", "global_batch": world * B},
             "roofline": roofline, "cpu_baseline": cpu,
             "final_loss": round(loss, 5), "setup_s": round(setup_s, 1),
-            "avg_nodes_per_batch": float(st[:, ops.ST_NODES].double().mean()),
-            "avg_edges_per_batch": float(st[:, ops.ST_EDGES].double().mean()),
+            "avg_nodes_per_batch": float(st[ops.ST_NODES]) / args.steps,
+            "avg_edges_per_batch": float(st[ops.ST_EDGES]) / args.steps,
+            "hip_graph": use_graph,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -26,16 +26,27 @@ constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kMaxFanout = 2048;
 
 // hop scratch words (int64) snapshotted by count_kernel for the other kernels of the hop
-enum { HI_NB = 0, HI_EBASE = 1, HI_FB = 2, HI_NF = 3, HI_WORDS = 8 };
+// HI_CTR / HI_STAMP: the call's effective Philox counter and table stamp (host value + the
+// optional device control block), resolved once by seed_kernel
+enum { HI_NB = 0, HI_EBASE = 1, HI_FB = 2, HI_NF = 3, HI_CTR = 4, HI_STAMP = 5, HI_WORDS = 8 };
 
 __device__ inline uint64_t enc(uint32_t stamp, uint32_t key) {
   return (static_cast<uint64_t>(0xFFFFFFFFu - stamp) << 32) | key;
 }
 
 __global__ void seed_kernel(const int64_t* __restrict__ seeds, int num_seeds, int64_t num_nodes,
-                            uint64_t* __restrict__ table, uint32_t stamp,
+                            uint64_t* __restrict__ table, uint32_t stamp_host, uint64_t ctr_host,
+                            const int64_t* __restrict__ ctrl, int64_t* __restrict__ hopinfo,
                             int64_t* __restrict__ node, int64_t* __restrict__ state) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t stamp = stamp_host;
+  uint64_t ctr = ctr_host;
+  int64_t seed_off = 0;
+  if (ctrl != nullptr) {
+    ctr += static_cast<uint64_t>(ctrl[SAGE_CTRL_COUNTER]);
+    stamp += static_cast<uint32_t>(ctrl[SAGE_CTRL_STAMP]);
+    seed_off = ctrl[SAGE_CTRL_SEED_OFFSET];
+  }
   if (i == 0) {
     for (int w = 0; w < SAGE_STATE_WORDS; ++w) {
       if (w != SAGE_ST_ERROR) state[w] = 0;
@@ -43,9 +54,11 @@ __global__ void seed_kernel(const int64_t* __restrict__ seeds, int num_seeds, in
     state[SAGE_ST_NODES] = num_seeds;
     state[SAGE_ST_FRONT_END] = num_seeds;
     state[SAGE_ST_HOP_NODES] = num_seeds;
+    hopinfo[HI_CTR] = static_cast<int64_t>(ctr);
+    hopinfo[HI_STAMP] = stamp;
   }
   if (i >= num_seeds) return;
-  int64_t s = seeds[i];
+  int64_t s = seeds[seed_off + i];
   if (s < 0 || s >= num_nodes) {
     atomicOr(reinterpret_cast<unsigned long long*>(&state[SAGE_ST_ERROR]), 4ull);
     s = 0;
@@ -83,8 +96,8 @@ __global__ void __launch_bounds__(kBlock)
 sample_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row,
               int64_t num_nodes, const int64_t* __restrict__ node,
               const int64_t* __restrict__ hopinfo, const int* __restrict__ off, int fanout,
-              int hop, uint32_t seed_lo, uint32_t seed_hi, uint32_t ctr_lo, uint32_t ctr_hi,
-              uint64_t* __restrict__ table, uint32_t stamp, int64_t edge_cap,
+              int hop, uint32_t seed_lo, uint32_t seed_hi,
+              uint64_t* __restrict__ table, int64_t edge_cap,
               int64_t* __restrict__ src, int64_t* __restrict__ dst, int64_t* __restrict__ eid,
               int64_t* __restrict__ seg_ptr, int64_t* __restrict__ state) {
   __shared__ uint32_t sh_chosen[BIG ? kWavesPerBlock * kMaxFanout : 1];
@@ -96,6 +109,9 @@ sample_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ ro
   const int64_t nb = hopinfo[HI_NB];
   const int64_t ebase = hopinfo[HI_EBASE];
   const int64_t fb = hopinfo[HI_FB];
+  const uint64_t ctr = static_cast<uint64_t>(hopinfo[HI_CTR]);
+  const uint32_t ctr_lo = static_cast<uint32_t>(ctr), ctr_hi = static_cast<uint32_t>(ctr >> 32);
+  const uint32_t stamp = static_cast<uint32_t>(hopinfo[HI_STAMP]);
   const int64_t t_local = fb + i;
   const int64_t w = node[t_local];
   const int64_t cs = colptr[w];
@@ -223,8 +239,9 @@ __global__ void relabel_kernel(const int64_t* __restrict__ hopinfo, const int* _
 __global__ void finalize_kernel(const int64_t* __restrict__ hopinfo, const int* __restrict__ off,
                                 int fcap, int64_t ecap, int64_t edge_cap, int64_t node_cap,
                                 const int* __restrict__ rank, const int64_t* __restrict__ node,
-                                uint64_t* __restrict__ table, uint32_t stamp, int hop,
+                                uint64_t* __restrict__ table, int hop,
                                 int64_t* __restrict__ state) {
+  const uint32_t stamp = static_cast<uint32_t>(hopinfo[HI_STAMP]);
   const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t nb = hopinfo[HI_NB];
   const int64_t ebase = hopinfo[HI_EBASE];
@@ -297,13 +314,14 @@ extern "C" size_t sage_sample_workspace_bytes(sage_i64 node_cap, sage_i64 edge_c
   return total + 256;
 }
 
-extern "C" int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, sage_i64 num_nodes,
-                                  const sage_i64* seeds, int num_seeds, const int* fanout_host,
-                                  int hops, uint64_t rng_seed, uint64_t rng_counter,
-                                  uint64_t* relabel_table, uint32_t stamp, sage_i64 node_cap,
-                                  sage_i64 edge_cap, sage_i64* node, sage_i64* src, sage_i64* dst,
-                                  sage_i64* eid, sage_i64* seg_ptr, sage_i64* state,
-                                  void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* row,
+                                       sage_i64 num_nodes, const sage_i64* seeds, int num_seeds,
+                                       const int* fanout_host, int hops, uint64_t rng_seed,
+                                       uint64_t rng_counter, uint64_t* relabel_table, uint32_t stamp,
+                                       const sage_i64* ctrl_dev, sage_i64 node_cap, sage_i64 edge_cap,
+                                       sage_i64* node, sage_i64* src, sage_i64* dst, sage_i64* eid,
+                                       sage_i64* seg_ptr, sage_i64* state, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(colptr && row && seeds && fanout_host && relabel_table && node && src && dst &&
                    eid && seg_ptr && state && workspace,
@@ -336,13 +354,12 @@ extern "C" int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, s
   void* scan_tmp = ws.take<char>(scan_bytes);
 
   const uint32_t seed_lo = static_cast<uint32_t>(rng_seed), seed_hi = static_cast<uint32_t>(rng_seed >> 32);
-  const uint32_t ctr_lo = static_cast<uint32_t>(rng_counter), ctr_hi = static_cast<uint32_t>(rng_counter >> 32);
 
   SAGE_CHECK_HIP(hipMemsetAsync(&state[SAGE_ST_ERROR], 0, sizeof(int64_t), stream), "state memset");
   {
     int grid = static_cast<int>(cdiv(num_seeds > 0 ? num_seeds : 1, kBlock));
     seed_kernel<<<grid, kBlock, 0, stream>>>(seeds, num_seeds, num_nodes, relabel_table, stamp,
-                                             node, state);
+                                             rng_counter, ctrl_dev, hopinfo, node, state);
     SAGE_CHECK_LAUNCH("seed_kernel");
   }
 
@@ -363,12 +380,12 @@ extern "C" int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, s
       int grid = static_cast<int>(cdiv(fcap, kWavesPerBlock));
       if (k > kWave) {
         sample_kernel<true><<<grid, kBlock, 0, stream>>>(
-            colptr, row, num_nodes, node, hopinfo, off, k, h, seed_lo, seed_hi, ctr_lo, ctr_hi,
-            relabel_table, stamp, edge_cap, src, dst, eid, seg_ptr, state);
+            colptr, row, num_nodes, node, hopinfo, off, k, h, seed_lo, seed_hi,
+            relabel_table, edge_cap, src, dst, eid, seg_ptr, state);
       } else {
         sample_kernel<false><<<grid, kBlock, 0, stream>>>(
-            colptr, row, num_nodes, node, hopinfo, off, k, h, seed_lo, seed_hi, ctr_lo, ctr_hi,
-            relabel_table, stamp, edge_cap, src, dst, eid, seg_ptr, state);
+            colptr, row, num_nodes, node, hopinfo, off, k, h, seed_lo, seed_hi,
+            relabel_table, edge_cap, src, dst, eid, seg_ptr, state);
       }
       SAGE_CHECK_LAUNCH("sample_kernel");
     }
@@ -389,7 +406,7 @@ extern "C" int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, s
     }
     finalize_kernel<<<static_cast<int>(cdiv(ecap > 0 ? ecap : 1, kBlock)), kBlock, 0, stream>>>(
         hopinfo, off, static_cast<int>(fcap), ecap, edge_cap, node_cap, rank, node, relabel_table,
-        stamp, h, state);
+        h, state);
     SAGE_CHECK_LAUNCH("finalize_kernel");
 
     // frontier of the next hop = nodes first seen in this one
@@ -398,6 +415,39 @@ extern "C" int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, s
   tail_kernel<<<static_cast<int>(cdiv(node_cap + 1, kBlock)), kBlock, 0, stream>>>(state, node_cap,
                                                                                     seg_ptr);
   SAGE_CHECK_LAUNCH("tail_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, sage_i64 num_nodes,
+                                  const sage_i64* seeds, int num_seeds, const int* fanout_host,
+                                  int hops, uint64_t rng_seed, uint64_t rng_counter,
+                                  uint64_t* relabel_table, uint32_t stamp, sage_i64 node_cap,
+                                  sage_i64 edge_cap, sage_i64* node, sage_i64* src, sage_i64* dst,
+                                  sage_i64* eid, sage_i64* seg_ptr, sage_i64* state,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  return sage_sample_fanout_ctrl(colptr, row, num_nodes, seeds, num_seeds, fanout_host, hops,
+                                 rng_seed, rng_counter, relabel_table, stamp, nullptr, node_cap,
+                                 edge_cap, node, src, dst, eid, seg_ptr, state, workspace,
+                                 workspace_bytes, stream);
+}
+
+namespace {
+__global__ void ctrl_advance_kernel(int64_t* ctrl, int64_t d_counter, int64_t d_stamp,
+                                    int64_t d_offset, int64_t offset_wrap) {
+  ctrl[SAGE_CTRL_COUNTER] += d_counter;
+  ctrl[SAGE_CTRL_STAMP] += d_stamp;
+  int64_t o = ctrl[SAGE_CTRL_SEED_OFFSET] + d_offset;
+  if (offset_wrap > 0 && o + d_offset > offset_wrap) o = 0;
+  ctrl[SAGE_CTRL_SEED_OFFSET] = o;
+}
+}  // namespace
+
+extern "C" int sage_ctrl_advance(sage_i64* ctrl_dev, sage_i64 d_counter, sage_i64 d_stamp,
+                                 sage_i64 d_offset, sage_i64 offset_wrap, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(ctrl_dev != nullptr, SAGE_EINVAL, "sage_ctrl_advance: ctrl_dev is NULL");
+  ctrl_advance_kernel<<<1, 1, 0, stream>>>(ctrl_dev, d_counter, d_stamp, d_offset, offset_wrap);
+  SAGE_CHECK_LAUNCH("ctrl_advance_kernel");
   return SAGE_OK;
 }
 

@@ -1,0 +1,27 @@
+"""Data-parallel helpers (one process per GPU, torch.distributed; backend nccl = RCCL over
+xGMI on the GPU box, gloo in the CPU tests).  The reference has no multi-GPU code at all
+(graphsage/settings.py:32 selects a single DEVICE); this is the one strategy SURVEY §8e adds:
+replicated graph + features, seed nodes sharded across ranks, ONE all-reduce of a flat
+gradient buffer per step."""
+import torch
+import torch.distributed as dist
+
+
+def shard_seeds(index, rank, world_size):
+    """Strided shard with equal counts on every rank (the tail that does not divide is dropped)."""
+    if world_size <= 1:
+        return index
+    per = index.numel() // world_size
+    return index[: per * world_size][rank::world_size]
+
+
+def batch_counter(epoch, batches_per_epoch, batch, rank, world_size):
+    """Philox batch counter: distinct for every (epoch, batch, rank)."""
+    return (epoch * batches_per_epoch + batch) * world_size + rank
+
+
+def all_reduce_flat(flat_grad, group=None):
+    """Sum the flat gradient buffer over ranks (the mean's 1/world is fused into Adam)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return flat_grad

@@ -17,22 +17,49 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
 import torch
 
 from . import ops
+from .dist import all_reduce_flat
 
 _REDUCE = {'mean': 'mean', 'sum': 'sum'}
 
 
-def flatten_parameters(model):
-    """Move every parameter of `model` into one flat fp32 buffer (views keep their shapes)."""
+def flatten_parameters(model, pad_to=16):
+    """Move every parameter of `model` into one flat fp32 buffer.  Matrices are stored with
+    their row stride rounded up to `pad_to` floats (602 -> 608) so that every row is 64-byte
+    aligned and the GEMM kernels can use 16-byte loads; the parameters become [out, in] views
+    of that storage (same values, same state_dict).  The padding stays zero under Adam."""
     params = [p for p in model.parameters()]
-    total = sum(p.numel() for p in params)
-    flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+    dev = params[0].device
+
+    def ld_of(p):
+        return (p.size(1) + pad_to - 1) // pad_to * pad_to if p.dim() == 2 else None
+
+    total = sum(p.size(0) * ld_of(p) if p.dim() == 2 else p.numel() for p in params)
+    flat = torch.zeros(total, dtype=torch.float32, device=dev)
+    layout = []
     off = 0
     for p in params:
-        n = p.numel()
-        flat[off:off + n].copy_(p.data.reshape(-1))
-        p.data = flat[off:off + n].view(p.shape)
+        if p.dim() == 2:
+            ld = ld_of(p)
+            n = p.size(0) * ld
+            view = flat[off:off + n].view(p.size(0), ld)[:, :p.size(1)]
+        else:
+            n = p.numel()
+            view = flat[off:off + n].view(p.shape)
+        view.copy_(p.data)
+        p.data = view
+        layout.append((off, n, tuple(p.shape), ld_of(p)))
         off += n
-    return flat
+    return flat, layout
+
+
+def views_like(flat, layout):
+    out = []
+    for off, n, shape, ld in layout:
+        if ld is not None:
+            out.append(flat[off:off + n].view(shape[0], ld)[:, :shape[1]])
+        else:
+            out.append(flat[off:off + n].view(shape))
+    return out
 
 
 class SageTrainEngine:
@@ -40,12 +67,15 @@ class SageTrainEngine:
                  eps=1e-8, weight_decay=0.0, world_size=1, process_group=None):
         if model.aggregator not in _REDUCE:
             raise NotImplementedError(f"engine supports {sorted(_REDUCE)}, got {model.aggregator}")
-        self.model, self.sampler = model, sampler
+        self.model = model
         self.reduce = _REDUCE[model.aggregator]
         self.features, self.labels = features, labels
         self.B = int(batch_size)
         self.L = len(model.layers)
-        fan = sampler.num_neighbors
+        self.graph = sampler.graph
+        self.fanout = list(sampler.num_neighbors)
+        self.rng_seed = sampler.seed
+        fan = self.fanout
         if len(fan) != self.L or any(k < 0 for k in fan):
             raise NotImplementedError("engine needs one non-negative fan-out per layer")
         dev = features.device
@@ -54,25 +84,26 @@ class SageTrainEngine:
         self.world_size, self.pg = world_size, process_group
         # capacities: hop_cap[h] = max nodes after hop h
         self.hop_cap = [self.B]
-        frontier = self.B
+        frontier, edge_cap = self.B, 0
         for k in fan:
             frontier = frontier * k
+            edge_cap += frontier
             self.hop_cap.append(self.hop_cap[-1] + frontier)
-        self.buf = sampler.buffers(self.B)
+        # the engine owns its sampler state (relabel table, stamps, buffers): a replayed graph
+        # advances the stamp on the device, so the table cannot be shared with eager callers
+        self.table = ops.new_relabel_table(self.graph.num_nodes, dev)
+        self.buf = ops.SampleBuffers(self.graph.num_nodes, self.hop_cap[-1], edge_cap, dev)
+        self.ctrl = torch.zeros(ops.CTRL_WORDS, dtype=torch.int64, device=dev)
+        self._stamp = 0
         st = self.buf.state
         self.n_dev = [st[ops.ST_HOP_NODES + h: ops.ST_HOP_NODES + h + 1] for h in range(self.L + 1)]
 
-        self.flat = flatten_parameters(model)
+        self.flat, self.layout = flatten_parameters(model)
         self.grad = torch.zeros_like(self.flat)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-        # gradient views with the parameters' shapes
-        self.gviews = {}
-        off = 0
-        for p in model.parameters():
-            self.gviews[p] = self.grad[off:off + p.numel()].view(p.shape)
-            off += p.numel()
+        self.gviews = dict(zip(model.parameters(), views_like(self.grad, self.layout)))
 
         def padded(rows, cols):
             ld = (cols + 15) // 16 * 16
@@ -94,23 +125,42 @@ class SageTrainEngine:
                 a['dagg'] = padded(t_cap, fin)
             self.act.append(a)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.seeds = torch.zeros(self.B, dtype=torch.int64, device=dev)
+        # running sums of the sampler's state block over replayed steps (batch sizes; a non-zero
+        # ST_ERROR sum means some batch reported an error)
+        self.state_sum = torch.zeros(ops.STATE_WORDS, dtype=torch.int64, device=dev)
         self.counter = 0
+        self.graphs = None
 
     # ------------------------------------------------------------------ pieces
-    def sample(self, seeds, counter):
-        self.seeds.copy_(seeds)
-        self.sampler.sample_async(self.seeds, counter=counter)
+    def sample(self, seeds, counter, ctrl=None):
+        """Enqueue the sampler for the batch `seeds[offset : offset+B]` (offset from ctrl or 0)."""
+        if ctrl is None:
+            self._stamp += 1
+            stamp = self._stamp
+        else:
+            stamp = 1          # the device control block carries the running stamp
+        ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed, counter,
+                          self.table, stamp, self.buf, ctrl=ctrl, num_seeds=self.B)
 
-    def forward_backward(self):
+    def gather_layer0(self):
+        a = self.act[0]
+        ops.gather_reduce_fwd(self.features, self.buf.seg_ptr, self.buf.src, a['t_cap'], self.reduce,
+                              node_map=self.buf.node, num_targets_dev=a['t_dev'], out=a['agg'],
+                              want_argmax=False)
+
+    def forward_backward(self, skip_gather0=False):
         L, buf = self.L, self.buf
         x, node_map = self.features, buf.node
         lib = ops
         for i, layer in enumerate(self.model.layers):
             a = self.act[i]
             t_cap, t_dev = a['t_cap'], a['t_dev']
-            lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=node_map,
-                                  num_targets_dev=t_dev, out=a['agg'], want_argmax=False)
+            if i == 0:
+                if not skip_gather0:
+                    self.gather_layer0()
+            else:
+                lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
+                                      num_targets_dev=t_dev, out=a['agg'], want_argmax=False)
             lib.linear_concat_fwd(a['agg'], layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
                                   m_dev=t_dev, rows2=node_map, out=a['z'])
             relu = i < L - 1
@@ -142,7 +192,7 @@ class SageTrainEngine:
 
     def all_reduce(self):
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.grad, group=self.pg)
+            all_reduce_flat(self.grad, self.pg)
 
     def optimizer_step(self):
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
@@ -150,7 +200,9 @@ class SageTrainEngine:
                       grad_scale=1.0 / self.world_size)
 
     def step(self, seeds, counter=None):
-        """One full training step on `seeds` (device int64[B]); returns the device loss tensor."""
+        """One eager training step on `seeds` (device int64[B]); returns the device loss tensor."""
+        if self.graphs is not None:
+            raise RuntimeError("engine was captured: use replay()")
         if counter is None:
             counter = self.counter
             self.counter += 1
@@ -158,4 +210,57 @@ class SageTrainEngine:
         self.forward_backward()
         self.all_reduce()
         self.optimizer_step()
+        return self.loss
+
+    # ------------------------------------------------------------------ HIP graph replay
+    def capture(self, seed_pool, counter0=0, counter_stride=1, split_gather=False):
+        """Capture the step into HIP graphs.  Batch b of the replay uses seeds
+        seed_pool[b*B:(b+1)*B] (wrapping at the end of the pool) and Philox counter
+        counter0 + b*counter_stride, exactly what step(seed_pool[...], counter) would use.
+
+        Graph 1: sampler (+ layer-0 gather unless split_gather) ; graph 2: the rest of
+        forward/backward ; [eager RCCL all-reduce when world_size > 1] ; graph 3: Adam + control
+        block advance.  split_gather leaves the layer-0 gather outside the graphs so a caller can
+        bracket that one kernel with events (bench.py's roofline probe)."""
+        if seed_pool.numel() < self.B:
+            raise RuntimeError("seed pool smaller than one batch")
+        self.seed_pool = seed_pool.contiguous()
+        self.split_gather = split_gather
+        pool_len = (self.seed_pool.numel() // self.B) * self.B
+        self.ctrl.zero_()
+        # stamps already used eagerly stay below the captured sequence
+        self.ctrl[ops.CTRL_STAMP] = self._stamp
+        torch.cuda.synchronize()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.stream(stream):
+            with torch.cuda.graph(g1, stream=stream):
+                self.sample(self.seed_pool, counter0, ctrl=self.ctrl)
+                self.state_sum.add_(self.buf.state)
+                if not split_gather:
+                    self.gather_layer0()
+            with torch.cuda.graph(g2, stream=stream):
+                self.forward_backward(skip_gather0=True)
+            with torch.cuda.graph(g3, stream=stream):
+                self.optimizer_step()
+                ops.ctrl_advance(self.ctrl, counter_stride, 1, self.B, pool_len)
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        self.graphs = (g1, g2, g3)
+        # capture does not execute: state_sum is still clean, ctrl still at the start
+        return self
+
+    def replay(self, before_gather=None, after_gather=None):
+        g1, g2, g3 = self.graphs
+        g1.replay()
+        if self.split_gather:
+            if before_gather is not None:
+                before_gather()
+            self.gather_layer0()
+            if after_gather is not None:
+                after_gather()
+        g2.replay()
+        self.all_reduce()
+        g3.replay()
         return self.loss

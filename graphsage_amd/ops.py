@@ -17,6 +17,7 @@ EPI_NONE, EPI_BIAS, EPI_RELU = 0, 1, 2
 
 ST_NODES, ST_EDGES, ST_FRONT_BEGIN, ST_FRONT_END, ST_ERROR = 0, 1, 2, 3, 4
 ST_HOP_NODES, ST_HOP_EDGES, STATE_WORDS = 8, 24, 40
+CTRL_COUNTER, CTRL_STAMP, CTRL_SEED_OFFSET, CTRL_WORDS = 0, 1, 2, 4
 
 
 def _stream():
@@ -124,10 +125,14 @@ def new_relabel_table(num_nodes, device):
     return torch.full((num_nodes,), -1, dtype=torch.int64, device=device)
 
 
-def sample_fanout(colptr, row, seeds, fanout, rng_seed, rng_counter, table, stamp, buf):
+def sample_fanout(colptr, row, seeds, fanout, rng_seed, rng_counter, table, stamp, buf,
+                  ctrl=None, num_seeds=None):
     """torch_sparse.neighbor_sample (reference samplers/uniform_loader.py:64-72).
 
     Enqueues the sampler; results land in `buf` (device), sizes in buf.state.  No sync.
+    ctrl: optional device control block (int64[CTRL_WORDS]) added to (rng_counter, stamp) and
+    giving the offset of the batch inside `seeds` — see sage_sample_fanout_ctrl; the caller
+    guarantees offset + num_seeds <= len(seeds).
     """
     lib = _lib.load()
     num_nodes = colptr.numel() - 1
@@ -135,17 +140,29 @@ def sample_fanout(colptr, row, seeds, fanout, rng_seed, rng_counter, table, stam
         raise RuntimeError("sample_fanout: buffers/table were sized for another graph")
     hops = len(fanout)
     fan = (ctypes.c_int * hops)(*[int(k) for k in fanout])
-    B = seeds.numel()
-    rc = lib.sage_sample_fanout(
+    B = seeds.numel() if num_seeds is None else int(num_seeds)
+    if B > seeds.numel() or B > buf.node_cap:
+        raise RuntimeError("sample_fanout: num_seeds exceeds the seed buffer / node capacity")
+    if ctrl is not None and ctrl.numel() < CTRL_WORDS:
+        raise RuntimeError("sample_fanout: control block too small")
+    rc = lib.sage_sample_fanout_ctrl(
         _vec(colptr, torch.int64, "colptr"), _vec(row, torch.int64, "row"), num_nodes,
         _vec(seeds, torch.int64, "seeds"), B, fan, hops,
         int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(rng_counter) & 0xFFFFFFFFFFFFFFFF,
-        _p(table, torch.int64, "relabel_table"), int(stamp), buf.node_cap, buf.edge_cap,
+        _p(table, torch.int64, "relabel_table"), int(stamp),
+        _vec(ctrl, torch.int64, "ctrl", allow_none=True), buf.node_cap, buf.edge_cap,
         _p(buf.node, torch.int64, "node"), _p(buf.src, torch.int64, "src"),
         _p(buf.dst, torch.int64, "dst"), _p(buf.eid, torch.int64, "eid"),
         _p(buf.seg_ptr, torch.int64, "seg_ptr"), _p(buf.state, torch.int64, "state"),
         c_void_p(buf.ws.data_ptr()), buf.ws_bytes, _stream())
     _lib.check(rc, "sage_sample_fanout")
+
+
+def ctrl_advance(ctrl, d_counter, d_stamp, d_offset, offset_wrap):
+    lib = _lib.load()
+    rc = lib.sage_ctrl_advance(_vec(ctrl, torch.int64, "ctrl", min_len=CTRL_WORDS), int(d_counter),
+                               int(d_stamp), int(d_offset), int(offset_wrap), _stream())
+    _lib.check(rc, "sage_ctrl_advance")
 
 
 def random_neighbor(colptr, row, start, rng_seed, rng_counter):

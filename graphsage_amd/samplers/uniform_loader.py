@@ -20,6 +20,7 @@ from torch import Tensor
 from .. import functional as SF
 from .. import ops, settings
 from ..data import Data
+from ..dist import batch_counter, shard_seeds
 
 
 def _device_for(data):
@@ -240,10 +241,7 @@ class NeighborLoader:
         self.batch_size, self.shuffle, self.drop_last = int(batch_size), shuffle, drop_last
         self.rank, self.world_size = int(rank), int(world_size)
         idx = get_input_node_indices(data, input_nodes)
-        if self.world_size > 1:
-            # data-parallel shard: strided, equal counts on every rank (tail dropped)
-            per = idx.numel() // self.world_size
-            idx = idx[: per * self.world_size][self.rank::self.world_size]
+        idx = shard_seeds(idx, self.rank, self.world_size)   # data-parallel shard
         self.dataset = _IndexDataset(idx)
         self._idx_dev = idx.to(self.neighbor_sampler.graph.device)
         self.epoch = 0
@@ -285,7 +283,7 @@ class NeighborLoader:
         for b in range(nb):
             index = order[b * self.batch_size: min((b + 1) * self.batch_size, n)].contiguous()
             # counter = f(epoch, batch, rank): distinct Philox streams for every batch of every rank
-            counter = ((self.epoch * nb + b) * self.world_size + self.rank)
+            counter = batch_counter(self.epoch, nb, b, self.rank, self.world_size)
             index_dev = index
             buf = sampler.sample_async(index_dev, counter=counter)
             state = buf.state.tolist()

@@ -120,6 +120,27 @@ int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, sage_i64 num
                        sage_i64* seg_ptr /*[node_cap+1]*/, sage_i64* state, void* workspace,
                        size_t workspace_bytes, void* stream);
 
+/* Same call with a DEVICE control block, for callers that replay the sampler from a HIP graph
+ * (host scalars are frozen at capture time): ctrl_dev[SAGE_CTRL_COUNTER] is added to
+ * rng_counter, ctrl_dev[SAGE_CTRL_STAMP] to stamp, and the seeds are read from
+ * seeds + ctrl_dev[SAGE_CTRL_SEED_OFFSET].  ctrl_dev = NULL gives sage_sample_fanout.
+ * sage_ctrl_advance (one tiny kernel, capturable) adds (d_counter, d_stamp, d_offset) to the
+ * block; the seed offset restarts at 0 when another batch of d_offset seeds would pass
+ * offset_wrap (> 0).  No counterpart in the reference: its sampler runs on the host. */
+#define SAGE_CTRL_COUNTER 0
+#define SAGE_CTRL_STAMP 1
+#define SAGE_CTRL_SEED_OFFSET 2
+#define SAGE_CTRL_WORDS 4
+int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* row, sage_i64 num_nodes,
+                            const sage_i64* seeds, int num_seeds, const int* fanout_host, int hops,
+                            uint64_t rng_seed, uint64_t rng_counter, uint64_t* relabel_table,
+                            uint32_t stamp, const sage_i64* ctrl_dev, sage_i64 node_cap,
+                            sage_i64 edge_cap, sage_i64* node, sage_i64* src, sage_i64* dst,
+                            sage_i64* eid, sage_i64* seg_ptr, sage_i64* state, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int sage_ctrl_advance(sage_i64* ctrl_dev, sage_i64 d_counter, sage_i64 d_stamp, sage_i64 d_offset,
+                      sage_i64 offset_wrap, void* stream);
+
 /* (f-2) one uniform random in-neighbour per start node; replaces
  * torch_cluster.random_walk(row, col, start, walk_length=1)[:,1] at samplers/utils.py:22.
  * A start with no neighbour returns itself (torch_cluster's behaviour).  Philox key =

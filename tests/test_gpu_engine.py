@@ -41,3 +41,41 @@ def test_engine_matches_module_path(dev, aggregator):
         for pa, pb in zip(model_a.parameters(), model_b.parameters()):
             torch.testing.assert_close(pb.data, pa.data, rtol=1e-4, atol=1e-5)
     assert int(engine.step_dev) == 4
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_graph_replay_matches_eager_steps(dev, split):
+    """HIP-graph replay (device control block drives seeds / Philox counter / stamp) runs the
+    same steps as eager engine.step, including the wrap at the end of the seed pool."""
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = planted_partition(2000, 40000, 24, 5, seed=4)
+    B = 32
+    graph = device_graph(data)
+    torch.manual_seed(1)
+    model_a = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
+    model_b = copy.deepcopy(model_a)
+    mk = lambda m: SageTrainEngine(m, NeighborSampler(data, [4, 3], seed=9), graph.features(data),
+                                   graph.labels(data), B, lr=1e-2)
+    eager, graphed = mk(model_a), mk(model_b)
+    pool = torch.randperm(2000, generator=torch.Generator().manual_seed(0))[:3 * B + 7].to(dev)  # 3 batches
+    graphed.step(pool[:B], counter=1000)      # an eager step before capture (stamps already in use)
+    eager.step(pool[:B], counter=1000)
+    graphed.capture(pool, counter0=5, counter_stride=2, split_gather=split)
+    for s in range(7):                         # wraps twice
+        b = s % 3
+        la = eager.step(pool[b * B:(b + 1) * B], counter=5 + 2 * s).clone()
+        lb = graphed.replay().clone()
+        assert torch.equal(eager.buf.node[:B], graphed.buf.node[:B])
+        assert torch.equal(eager.buf.state, graphed.buf.state)
+        n, e = int(eager.buf.state[0]), int(eager.buf.state[1])
+        assert torch.equal(eager.buf.node[:n], graphed.buf.node[:n])
+        assert torch.equal(eager.buf.src[:e], graphed.buf.src[:e])
+        torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(graphed.flat, eager.flat, rtol=1e-4, atol=1e-6)
+    assert int(graphed.state_sum[4]) == 0 and int(graphed.step_dev) == 8
+    with pytest.raises(RuntimeError):
+        graphed.step(pool[:B])
