@@ -493,3 +493,49 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
                             float(beta2), float(eps), float(weight_decay), float(grad_scale),
                             _count(step_dev, "step_dev"), _stream())
     _lib.check(rc, "sage_adam_step")
+
+
+# ------------------------------------------------------------------------------- a-7
+def segment_slots(seg_ptr, src, num_targets, n_in, node_map=None):
+    """Per target, the row ids of its first n_in inputs (padded with the first) + nonempty mask."""
+    lib = _lib.load()
+    T = int(num_targets)
+    if seg_ptr.numel() < T + 1:
+        raise RuntimeError("segment_slots: seg_ptr shorter than num_targets+1")
+    slots = torch.empty(T * n_in, dtype=torch.int64, device=seg_ptr.device)
+    nonempty = torch.empty(T, dtype=torch.float32, device=seg_ptr.device)
+    rc = lib.sage_segment_slots(_vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"),
+                                _vec(node_map, torch.int64, "node_map", allow_none=True), T, int(n_in),
+                                _vec(slots, torch.int64, "slots"), _vec(nonempty, torch.float32, "nonempty"),
+                                _stream())
+    _lib.check(rc, "sage_segment_slots")
+    return slots, nonempty
+
+
+def lstm_cell0_fwd(gates, nonempty, num_features):
+    lib = _lib.load()
+    gp, ld_g = _mat(gates, "gates")
+    m = gates.size(0)
+    if gates.size(1) != 4 * num_features or nonempty.numel() < m:
+        raise RuntimeError("lstm_cell0_fwd: shape mismatch")
+    h = torch.empty((m, num_features), dtype=torch.float32, device=gates.device)
+    hp, ld_h = _mat(h, "h")
+    rc = lib.sage_lstm_cell0_fwd(gp, ld_g, _vec(nonempty, torch.float32, "nonempty"), m, int(num_features),
+                                 hp, ld_h, _stream())
+    _lib.check(rc, "sage_lstm_cell0_fwd")
+    return h
+
+
+def lstm_cell0_bwd(gates, nonempty, dh, num_features):
+    lib = _lib.load()
+    gp, ld_g = _mat(gates, "gates")
+    dp, ld_dh = _mat(dh, "dh")
+    m = gates.size(0)
+    if gates.size(1) != 4 * num_features or dh.shape != (m, num_features) or nonempty.numel() < m:
+        raise RuntimeError("lstm_cell0_bwd: shape mismatch")
+    dgates = torch.empty_like(gates)
+    op, ld_dg = _mat(dgates, "dgates")
+    rc = lib.sage_lstm_cell0_bwd(gp, ld_g, _vec(nonempty, torch.float32, "nonempty"), dp, ld_dh, m,
+                                 int(num_features), op, ld_dg, _stream())
+    _lib.check(rc, "sage_lstm_cell0_bwd")
+    return dgates

@@ -47,7 +47,7 @@ def scatter_ref(x_j, index, dim_size, reduce):
 
 
 def sage_forward(x, edge_index, lin_l, lin_r=None, aggregator="mean", pool_w=None, pool_b=None,
-                 normalize=True):
+                 normalize=True, lstm=None):
     """One SAGE layer on all rows of x.  lin_l/lin_r: [out, in] weights, no bias
     (reference layers/sage.py:78-81).  gcn: self-loops for unique targets, no root term
     (:62-65, :114-117).  *_pool: relu(pool(x_j)) per edge before the reduce (:201-207)."""
@@ -56,6 +56,11 @@ def sage_forward(x, edge_index, lin_l, lin_r=None, aggregator="mean", pool_w=Non
     if aggregator == "gcn":
         roots = torch.unique(ei[1])
         ei = torch.cat([ei, torch.stack([roots, roots], dim=0)], dim=1)
+    if aggregator == "lstm":
+        # lstm = dict(n_in, w_ih, w_hh, b_ih, b_hh); rows without in-edges are 0 (:121-122)
+        out = lstm_aggregate_ref(x, ei, n, lstm["n_in"], lstm["w_ih"], lstm["w_hh"], lstm["b_ih"], lstm["b_hh"])
+        out = F.linear(out, lin_l) + F.linear(x, lin_r)
+        return F.normalize(out, p=2.0, dim=-1) if normalize else out
     x_j = x.index_select(0, ei[0])
     if aggregator in ("mean", "max", "sum"):
         reduce = aggregator
@@ -116,3 +121,29 @@ def unsup_loss(out, pos_out, neg_out):
     pos_loss = F.logsigmoid((out * pos_out).sum(-1)).mean()
     neg_loss = F.logsigmoid(-(out * neg_out).sum(-1)).mean()
     return -pos_loss - neg_loss
+
+
+def lstm_aggregate_ref(x, edge_index, num_nodes, n_in, w_ih, w_hh, b_ih, b_hh):
+    """The computation reference layers/sage.py:147-193 is after, made well-defined (per target,
+    neighbours in edge order grouped by target, first n_in kept, padded with the first row,
+    flattened, ONE LSTMCell step from a zero state; no in-edge -> 0).  Parity unpinned: the
+    reference's own code is disabled upstream as broken (settings.py:48-50)."""
+    Fdim = x.size(1)
+    order = torch.argsort(edge_index[1], stable=True)
+    src, dst = edge_index[0][order], edge_index[1][order]
+    out = torch.zeros(num_nodes, Fdim, dtype=x.dtype)
+    rows_out = []
+    for t in range(num_nodes):
+        nb = src[dst == t][:n_in]
+        if nb.numel() == 0:
+            rows_out.append(torch.zeros(Fdim, dtype=x.dtype))
+            continue
+        rows = x[nb]
+        if rows.size(0) < n_in:
+            rows = torch.cat([rows, rows[0:1].repeat(n_in - rows.size(0), 1)])
+        flat = rows.reshape(1, -1)
+        gates = F.linear(flat, w_ih, b_ih) + F.linear(torch.zeros(1, Fdim, dtype=x.dtype), w_hh, b_hh)
+        i, f, g, o = gates.chunk(4, dim=1)
+        c = torch.sigmoid(i) * torch.tanh(g)
+        rows_out.append((torch.sigmoid(o) * torch.tanh(c)).squeeze(0))
+    return torch.stack(rows_out) if rows_out else out

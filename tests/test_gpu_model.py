@@ -127,3 +127,34 @@ def test_train_step_gradients_match_oracle(dev):
         for m, p in zip(model.layers, ref_layers):
             torch.testing.assert_close(m.lin_l.weight.grad.cpu(), p["lin_l"].grad, rtol=1e-3, atol=1e-5)
             torch.testing.assert_close(m.lin_r.weight.grad.cpu(), p["lin_r"].grad, rtol=1e-3, atol=1e-5)
+
+
+def test_lstm_aggregator_matches_oracle(dev):
+    """a-7: parity unpinned against the reference (its lstm code is disabled as broken); the
+    kernels are checked against the oracle's well-defined restatement."""
+    from graphsage_amd.layers import SAGE
+    n, e, fin, fout, n_in = 120, 700, 12, 8, 4
+    ei = torch.from_numpy(random_graph(n, e, seed=8, isolated=5))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(n, fin, generator=g)
+    torch.manual_seed(3)
+    layer = SAGE(fin, fout, 'lstm')
+    layer.lstm_n_inputs = n_in
+    layer.lstm = torch.nn.LSTMCell(n_in * fin, fin)
+    layer = layer.to(dev)
+    assert {"lstm.weight_ih", "lstm.weight_hh", "lstm.bias_ih", "lstm.bias_hh"} <= set(layer.state_dict())
+    cpu = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in layer.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    lstm = dict(n_in=n_in, w_ih=cpu["lstm.weight_ih"], w_hh=cpu["lstm.weight_hh"], b_ih=cpu["lstm.bias_ih"],
+                b_hh=cpu["lstm.bias_hh"])
+    want = sage_ref.sage_forward(xr, ei, cpu["lin_l.weight"], cpu["lin_r.weight"], "lstm", lstm=lstm)
+    xd = x.to(dev).requires_grad_(True)
+    out = layer(xd, ei.to(dev))
+    torch.testing.assert_close(out.cpu(), want.detach(), rtol=1e-4, atol=ATOL)
+    dout = torch.randn(n, fout, generator=g)
+    want.backward(dout)
+    out.backward(dout.to(dev))
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, rtol=1e-3, atol=ATOL)
+    torch.testing.assert_close(layer.lstm.weight_ih.grad.cpu(), cpu["lstm.weight_ih"].grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(layer.lstm.bias_ih.grad.cpu(), cpu["lstm.bias_ih"].grad, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(layer.lin_l.weight.grad.cpu(), cpu["lin_l.weight"].grad, rtol=1e-3, atol=1e-4)

@@ -167,3 +167,17 @@ def test_pruned_equals_unpruned_on_seed_rows():
     ei2 = eib[:, :e1]
     out = sage_ref.sage_forward(h1, ei2, layers[1]["lin_l"], layers[1]["lin_r"], "mean")[:40]
     assert torch.allclose(full, out, atol=1e-6)
+
+
+def test_lstm_aggregate_ref_uses_torch_lstmcell_semantics():
+    """The oracle's zero-state cell equals torch.nn.LSTMCell on the flattened, padded input."""
+    g = torch.Generator().manual_seed(0)
+    Fdim, n_in = 4, 3
+    cell = torch.nn.LSTMCell(n_in * Fdim, Fdim)
+    x = torch.randn(5, Fdim, generator=g)
+    ei = torch.tensor([[1, 2, 3, 4, 0], [0, 0, 0, 0, 2]])      # 0 <- {1,2,3,4} (truncated to 3), 2 <- {0} (padded)
+    out = sage_ref.lstm_aggregate_ref(x, ei, 5, n_in, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+    h0, _ = cell(torch.cat([x[1], x[2], x[3]]).unsqueeze(0))
+    h2, _ = cell(torch.cat([x[0], x[0], x[0]]).unsqueeze(0))
+    assert torch.allclose(out[0], h0.squeeze(0), atol=1e-6) and torch.allclose(out[2], h2.squeeze(0), atol=1e-6)
+    assert bool((out[1] == 0).all()) and bool((out[3] == 0).all())
