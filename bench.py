@@ -153,18 +153,13 @@ def main():
             else:
                 engine.replay()
     else:
+        # same pipeline driven eagerly: sampler of step s+1 on the side stream during step s
+        engine.prefetch(seeds_of(0), counter_of(0))
+
         def run_step(s, timed):
-            engine.sample(seeds_of(s), counter_of(s))
-            engine.state_sum.add_(engine.buf.state)
-            if probe and timed:
-                ev[cur["i"]][0].record()
-                engine.gather_layer0()
-                ev[cur["i"]][1].record()
-            else:
-                engine.gather_layer0()
-            engine.forward_backward(skip_gather0=True)
-            engine.all_reduce()
-            engine.optimizer_step()
+            b = (lambda: ev[cur["i"]][0].record()) if (probe and timed) else None
+            a = (lambda: ev[cur["i"]][1].record()) if (probe and timed) else None
+            engine.pipelined_step(seeds_of(s + 1), counter_of(s + 1), b, a)
 
     for s in range(args.warmup):
         run_step(s, False)

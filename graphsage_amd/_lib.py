@@ -50,6 +50,8 @@ SIGNATURES = {
                                      _P, c_int64, _P]),
     "sage_softmax_xent": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, c_int64,
                                   _P]),
+    "sage_logits_xent_fused": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P,
+                                       _P, c_int64, _P, _P, _P]),
     "sage_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_float, _P, _P]),
 }

@@ -16,6 +16,12 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// used instead of hipMemsetAsync so that every node a caller captures in a HIP graph is a kernel
+__global__ void zero_i64_kernel(int64_t* p, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 __global__ void make_keys_kernel(const int64_t* __restrict__ edge_row,
                                  const int64_t* __restrict__ edge_col, int64_t num_edges,
                                  int64_t num_nodes, int64_t* __restrict__ keys,
@@ -103,7 +109,11 @@ extern "C" int sage_csc_build(const sage_i64* edge_row, const sage_i64* edge_col
   void* scan_tmp = ws.take<char>(scan_bytes);
 
   // counts[0..N-1] histogram, counts[N] = 0 (scan total slot), counts[N+1] = bad-edge counter
-  SAGE_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (num_nodes + 2), stream), "counts memset");
+  {
+    const int64_t nz = (num_nodes + 2);
+    zero_i64_kernel<<<static_cast<unsigned>(cdiv(nz, kBlock)), kBlock, 0, stream>>>(counts, nz);
+    SAGE_CHECK_LAUNCH("zero_i64_kernel");
+  }
   if (num_edges > 0) {
     SAGE_REQUIRE(edge_row && edge_col && row_out && perm, SAGE_EINVAL,
                  "sage_csc_build: NULL pointer argument");

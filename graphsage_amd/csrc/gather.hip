@@ -22,6 +22,12 @@ namespace sage {
 namespace {
 
 constexpr int kBlock = 256;
+
+// used instead of hipMemsetAsync so that every node a caller captures in a HIP graph is a kernel
+__global__ void zero_i64_kernel(int64_t* p, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kRowsInFlight = 4;
 
@@ -508,7 +514,11 @@ extern "C" int sage_coo_to_csr(const sage_i64* edge_src, const sage_i64* edge_ds
   size_t scan_bytes = scan64_temp_bytes(static_cast<size_t>(num_targets) + 2);
   void* scan_tmp = ws.take<char>(scan_bytes);
 
-  SAGE_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int64_t) * (num_targets + 1), stream), "counts memset");
+  {
+    const int64_t nz = (num_targets + 1);
+    zero_i64_kernel<<<static_cast<unsigned>(cdiv(nz, kBlock)), kBlock, 0, stream>>>(counts, nz);
+    SAGE_CHECK_LAUNCH("zero_i64_kernel");
+  }
   if (num_edges > 0) {
     SAGE_REQUIRE(edge_src && edge_dst && src_sorted && perm, SAGE_EINVAL,
                  "sage_coo_to_csr: NULL pointer argument");

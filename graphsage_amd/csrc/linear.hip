@@ -347,6 +347,176 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream, const char* w
   return launch_gemm_vec<A_KC, B_KC, 1>(g, splits, stream, what);
 }
 
+
+// ======================================================================================
+// Skinny contractions: one of the dimensions is <= 64 (the class logits: 41 on Reddit, 7 on
+// Cora).  An MFMA tile grid has only M/64 workgroups there and every K-step is a latency-bound
+// round trip, so these run as plain VALU kernels with one wave per row instead: the whole
+// weight matrix (<= 64 rows) stays in L1/L2 and every lane streams 16-byte vectors.
+// ======================================================================================
+struct SkinnyArgs {
+  Segment seg[2];
+  int nseg;
+  int64_t m;
+  const int64_t* m_dev;
+  int n;
+  float* out;
+  int64_t ld_out;
+  const float* bias;
+  int epilogue;
+  int accumulate;
+};
+
+__device__ inline float wave_sum64(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ inline float4 load4_guard(const float* p, int k0, int k_lim) {
+  float4 v = *reinterpret_cast<const float4*>(p + k0);  // stays inside the padded row stride
+  if (k0 + 1 >= k_lim) v.y = 0.f;
+  if (k0 + 2 >= k_lim) v.z = 0.f;
+  if (k0 + 3 >= k_lim) v.w = 0.f;
+  return v;
+}
+
+// out[m][n] = sum_seg sum_k a[rows(m)][k] * w[n][k]  (n <= NT <= 64): one wave per row m
+template <int NT>
+__global__ void __launch_bounds__(kThreads) skinny_fwd_kernel(SkinnyArgs s) {
+  int64_t m_lim = s.m;
+  if (s.m_dev != nullptr) {
+    const int64_t v = *s.m_dev;
+    if (v < m_lim) m_lim = v;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t m = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6);
+  if (m >= m_lim) return;
+  float acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) acc[n] = 0.f;
+  for (int sg = 0; sg < s.nseg; ++sg) {
+    const Segment& g = s.seg[sg];
+    const int64_t r = g.a.rowmap != nullptr ? g.a.rowmap[m] : m;
+    const float* arow = g.a.p + r * g.a.ld;
+    for (int k0 = lane * 4; k0 < g.k; k0 += 256) {
+      const float4 av = load4_guard(arow, k0, g.k);
+      // branch-free over n (rows beyond s.n re-read the last row and are discarded) so that the
+      // NT independent weight loads are issued back to back instead of one round trip each
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int nc = n < s.n ? n : s.n - 1;
+        const float4 wv = load4_guard(g.b.p + nc * g.b.ld, k0, g.k);
+        acc[n] += av.x * wv.x + av.y * wv.y + av.z * wv.z + av.w * wv.w;
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    if (n < s.n) {
+      const float t = wave_sum64(acc[n]);
+      if (lane == n) mine = t;
+    }
+  }
+  if (lane < s.n) {
+    if (s.epilogue & SAGE_EPI_BIAS) mine += s.bias[lane];
+    if (s.epilogue & SAGE_EPI_RELU) mine = fmaxf(mine, 0.f);
+    s.out[m * s.ld_out + lane] = mine;
+  }
+}
+
+// da[m][k] (+)= sum_n dout[m][n] * w[n][k]  (n <= 64): one wave per row m, lanes over k
+__global__ void __launch_bounds__(kThreads) skinny_dinput_kernel(SkinnyArgs s) {
+  int64_t m_lim = s.m;
+  if (s.m_dev != nullptr) {
+    const int64_t v = *s.m_dev;
+    if (v < m_lim) m_lim = v;
+  }
+  const int lane = threadIdx.x & 63;
+  const int64_t m = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6);
+  if (m >= m_lim) return;
+  const Segment& g = s.seg[0];       // a = dout [m][n], b = w [n][k]; g.k = n (contraction)
+  const float* drow = g.a.p + m * g.a.ld;
+  const int K = s.n;                 // output columns
+  for (int k0 = lane * 4; k0 < K; k0 += 256) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < g.k; ++n) {
+      const float d = drow[n];
+      const float4 wv = *reinterpret_cast<const float4*>(g.b.p + n * g.b.ld + k0);
+      acc.x += d * wv.x; acc.y += d * wv.y; acc.z += d * wv.z; acc.w += d * wv.w;
+    }
+    float* o = s.out + m * s.ld_out + k0;
+    const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (k0 + j < K) o[j] = s.accumulate ? o[j] + v[j] : v[j];
+    }
+  }
+}
+
+// dw[n][k] += sum_m dout[m][n] * a[rows(m)][k]  (n <= 64): thread per column k, block per
+// (256 columns, group of 8 output rows, slice of m); slices are combined with fp32 atomics
+constexpr int kDwRows = 8;
+__global__ void __launch_bounds__(kThreads)
+skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ a,
+                      int64_t ld_a, const int64_t* __restrict__ rows, int64_t m,
+                      const int64_t* __restrict__ m_dev, int n, int k, int m_chunk,
+                      float* __restrict__ dw, int64_t ld_dw, float* __restrict__ dbias) {
+  int64_t m_lim = m;
+  if (m_dev != nullptr) {
+    const int64_t v = *m_dev;
+    if (v < m_lim) m_lim = v;
+  }
+  const int64_t m_beg = static_cast<int64_t>(blockIdx.z) * m_chunk;
+  int64_t m_end = m_beg + m_chunk;
+  if (m_end > m_lim) m_end = m_lim;
+  if (m_beg >= m_end) return;
+  const int col = blockIdx.x * kThreads + threadIdx.x;
+  const int n0 = blockIdx.y * kDwRows;
+  int nidx[kDwRows];
+#pragma unroll
+  for (int i = 0; i < kDwRows; ++i) nidx[i] = n0 + i < n ? n0 + i : n - 1;
+  float acc[kDwRows];
+#pragma unroll
+  for (int i = 0; i < kDwRows; ++i) acc[i] = 0.f;
+  constexpr int U = 4;  // rows of m in flight
+  for (int64_t mm = m_beg; mm < m_end; mm += U) {
+    float av[U];
+    int64_t mc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mc[u] = mm + u < m_end ? mm + u : m_end - 1;
+      const int64_t r = rows != nullptr ? rows[mc[u]] : mc[u];
+      av[u] = (col < k && mm + u < m_end) ? a[r * ld_a + col] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float* drow = dout + mc[u] * ld_dout;
+#pragma unroll
+      for (int i = 0; i < kDwRows; ++i) acc[i] += drow[nidx[i]] * av[u];
+    }
+  }
+  if (col < k) {
+#pragma unroll
+    for (int i = 0; i < kDwRows; ++i) {
+      if (n0 + i < n) atomicAdd(dw + (n0 + i) * ld_dw + col, acc[i]);
+    }
+  }
+  if (dbias != nullptr && blockIdx.x == 0 && threadIdx.x < kDwRows && n0 + threadIdx.x < n) {
+    float sb = 0.f;
+    for (int64_t mm = m_beg; mm < m_end; ++mm) sb += dout[mm * ld_dout + n0 + threadIdx.x];
+    atomicAdd(dbias + n0 + threadIdx.x, sb);
+  }
+}
+
+template <int NT>
+int launch_skinny_fwd(const SkinnyArgs& s, hipStream_t stream) {
+  skinny_fwd_kernel<NT><<<static_cast<unsigned>(cdiv(s.m, kThreads / 64)), kThreads, 0, stream>>>(s);
+  SAGE_CHECK_LAUNCH("skinny_fwd_kernel");
+  return SAGE_OK;
+}
+
 }  // namespace
 }  // namespace sage
 
@@ -386,6 +556,20 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
   g.ld_out = ld_out;
   g.bias = bias;
   g.epilogue = epilogue;
+  bool all4 = true;
+  for (int s = 0; s < g.nseg; ++s) all4 = all4 && g.seg[s].a.vec == 4 && g.seg[s].b.vec == 4;
+  if (n <= 64 && all4) {
+    SkinnyArgs s = {};
+    s.seg[0] = g.seg[0];
+    s.seg[1] = g.seg[1];
+    s.nseg = g.nseg;
+    s.m = m; s.m_dev = m_dev; s.n = n; s.out = out; s.ld_out = ld_out; s.bias = bias; s.epilogue = epilogue;
+    if (n <= 8) return launch_skinny_fwd<8>(s, stream);
+    if (n <= 16) return launch_skinny_fwd<16>(s, stream);
+    if (n <= 32) return launch_skinny_fwd<32>(s, stream);
+    if (n <= 48) return launch_skinny_fwd<48>(s, stream);
+    return launch_skinny_fwd<64>(s, stream);
+  }
   return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");
 }
 
@@ -409,6 +593,15 @@ extern "C" int sage_linear_dinput(const float* dout, sage_i64 ld_dout, const flo
   g.out = da;
   g.ld_out = ld_da;
   g.atomic_out = accumulate ? 1 : 0;
+  if (n <= 64 && g.seg[0].b.vec == 4) {
+    SkinnyArgs s = {};
+    s.seg[0] = g.seg[0];
+    s.nseg = 1;
+    s.m = m; s.m_dev = m_dev; s.n = k; s.out = da; s.ld_out = ld_da; s.accumulate = accumulate ? 1 : 0;
+    skinny_dinput_kernel<<<static_cast<unsigned>(cdiv(m, kThreads / 64)), kThreads, 0, stream>>>(s);
+    SAGE_CHECK_LAUNCH("skinny_dinput_kernel");
+    return SAGE_OK;
+  }
   return launch_gemm<true, false>(g, 1, stream, "gemm_kernel(dinput)");
 }
 
@@ -435,6 +628,19 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   g.ld_out = ld_dw;
   g.atomic_out = 1;
   g.colsum = dbias;
+  if (n <= 64) {
+    const int64_t col_blocks = cdiv(k, kThreads);
+    int64_t sp = cdiv(m, 32);       // >= 32 rows of m per block, <= 16 slices (atomic contention)
+    if (sp > 16) sp = 16;
+    if (sp < 1) sp = 1;
+    const int m_chunk = static_cast<int>(cdiv(m, sp));
+    dim3 grid(static_cast<unsigned>(col_blocks), static_cast<unsigned>(cdiv(n, kDwRows)),
+              static_cast<unsigned>(cdiv(m, m_chunk)));
+    skinny_dweight_kernel<<<grid, kThreads, 0, stream>>>(dout, ld_dout, a, ld_a, rows, m, m_dev, n, k,
+                                                         m_chunk, dw, ld_dw, dbias);
+    SAGE_CHECK_LAUNCH("skinny_dweight_kernel");
+    return SAGE_OK;
+  }
   // split the contraction so that the grid covers the chip about twice
   const int64_t tiles = cdiv(n, 64) * cdiv(k, k > 64 ? 128 : 64);
   int64_t splits = cdiv(512, tiles);

@@ -157,6 +157,78 @@ softmax_xent_kernel(const float* __restrict__ logits, int64_t ld_logits,
   }
 }
 
+// Last layer, fused: y = normalize(z); loss_r = CE(y, label); dz = d loss / d z.  Everything is
+// row-local, so one wave per row replaces l2norm_fwd + softmax_xent + l2norm_bwd (and the
+// single-workgroup loss kernel's serial walk over the rows).
+__global__ void __launch_bounds__(kBlock)
+logits_xent_fused_kernel(const float* __restrict__ z, int64_t ld_z,
+                         const int64_t* __restrict__ labels, const int64_t* __restrict__ label_rows,
+                         int64_t m, int n, float grad_scale, float* __restrict__ y, int64_t ld_y,
+                         float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
+                         float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (r >= m) return;
+  const int64_t lab = labels[label_rows != nullptr ? label_rows[r] : r];
+  const float* zr = z + r * ld_z;
+  float ss = 0.f;
+  for (int f = lane; f < n; f += kWave) {
+    const float v = zr[f];
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), kNormEps);
+  const float inv = 1.f / denom;
+  const bool clamped = inv >= 1.f / kNormEps;
+  float mx = -INFINITY;
+  for (int f = lane; f < n; f += kWave) mx = fmaxf(mx, zr[f] / denom);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int f = lane; f < n; f += kWave) se += expf(zr[f] / denom - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  const float scale = grad_scale / static_cast<float>(m);
+  float dot = 0.f, at_label = 0.f;
+  for (int f = lane; f < n; f += kWave) {
+    const float yv = zr[f] / denom;
+    float g = expf(yv - lse);
+    if (f == lab) {
+      g -= 1.f;
+      at_label = yv;
+    }
+    dot += yv * g * scale;
+  }
+  dot = clamped ? 0.f : wave_sum(dot);
+  at_label = wave_sum(at_label);
+  if (lane == 0) {
+    if (inv_norm != nullptr) inv_norm[r] = inv;
+    row_loss[r] = (lab >= 0 && lab < n) ? lse - at_label : 0.f;
+  }
+  for (int f = lane; f < n; f += kWave) {
+    const float yv = zr[f] / denom;
+    float g = expf(yv - lse);
+    if (f == lab) g -= 1.f;
+    g *= scale;
+    if (y != nullptr) y[r * ld_y + f] = yv;
+    dz[r * ld_dz + f] = (g - yv * dot) * inv;
+  }
+}
+
+// loss = mean(row_loss[0:m]) — one workgroup, fixed order: bitwise reproducible
+__global__ void __launch_bounds__(kBlock)
+mean_reduce_kernel(const float* __restrict__ v, int64_t m, float* __restrict__ out) {
+  __shared__ float partial[kBlock];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < m; i += kBlock) s += v[i];
+  partial[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) partial[threadIdx.x] += partial[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = partial[0] / static_cast<float>(m);
+}
+
 __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                             float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                             int64_t numel, float lr, float beta1, float beta2, float eps,
@@ -245,5 +317,23 @@ extern "C" int sage_adam_step(float* param, const float* grad, float* exp_avg, f
   }
   bump_step_kernel<<<1, 1, 0, stream>>>(step_dev);
   SAGE_CHECK_LAUNCH("bump_step_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_logits_xent_fused(const float* z, sage_i64 ld_z, const sage_i64* labels,
+                                      const sage_i64* label_rows, sage_i64 m, int n,
+                                      float grad_scale, float* y, sage_i64 ld_y, float* inv_norm,
+                                      float* dz, sage_i64 ld_dz, float* row_loss, float* loss,
+                                      void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m > 0 && n > 0 && ld_z >= n && ld_dz >= n && (y == nullptr || ld_y >= n), SAGE_EINVAL,
+               "sage_logits_xent_fused: bad shape");
+  SAGE_REQUIRE(z && labels && dz && row_loss && loss, SAGE_EINVAL,
+               "sage_logits_xent_fused: NULL pointer argument");
+  logits_xent_fused_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+      z, ld_z, labels, label_rows, m, n, grad_scale, y, ld_y, inv_norm, dz, ld_dz, row_loss);
+  SAGE_CHECK_LAUNCH("logits_xent_fused_kernel");
+  mean_reduce_kernel<<<1, kBlock, 0, stream>>>(row_loss, m, loss);
+  SAGE_CHECK_LAUNCH("mean_reduce_kernel");
   return SAGE_OK;
 }

@@ -34,6 +34,10 @@ __device__ inline uint64_t enc(uint32_t stamp, uint32_t key) {
   return (static_cast<uint64_t>(0xFFFFFFFFu - stamp) << 32) | key;
 }
 
+__global__ void zero_words_kernel(int64_t* p, int n) {
+  if (threadIdx.x < n) p[threadIdx.x] = 0;
+}
+
 __global__ void seed_kernel(const int64_t* __restrict__ seeds, int num_seeds, int64_t num_nodes,
                             uint64_t* __restrict__ table, uint32_t stamp_host, uint64_t ctr_host,
                             const int64_t* __restrict__ ctrl, int64_t* __restrict__ hopinfo,
@@ -355,7 +359,10 @@ extern "C" int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* r
 
   const uint32_t seed_lo = static_cast<uint32_t>(rng_seed), seed_hi = static_cast<uint32_t>(rng_seed >> 32);
 
-  SAGE_CHECK_HIP(hipMemsetAsync(&state[SAGE_ST_ERROR], 0, sizeof(int64_t), stream), "state memset");
+  // a kernel, not hipMemsetAsync: a small memset node replayed from a HIP graph was observed to
+  // write a stale fill value on ROCm 7.2 (0x20.. instead of 0)
+  zero_words_kernel<<<1, 64, 0, stream>>>(&state[SAGE_ST_ERROR], 1);
+  SAGE_CHECK_LAUNCH("zero_words_kernel");
   {
     int grid = static_cast<int>(cdiv(num_seeds > 0 ? num_seeds : 1, kBlock));
     seed_kernel<<<grid, kBlock, 0, stream>>>(seeds, num_seeds, num_nodes, relabel_table, stamp,
@@ -402,7 +409,8 @@ extern "C" int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* r
           src, node, state);
       SAGE_CHECK_LAUNCH("relabel_kernel");
     } else {
-      SAGE_CHECK_HIP(hipMemsetAsync(rank, 0, sizeof(int), stream), "rank memset");
+      zero_words_kernel<<<1, 64, 0, stream>>>(reinterpret_cast<int64_t*>(rank), 1);  // rank[0] = 0
+      SAGE_CHECK_LAUNCH("zero_words_kernel");
     }
     finalize_kernel<<<static_cast<int>(cdiv(ecap > 0 ? ecap : 1, kBlock)), kBlock, 0, stream>>>(
         hopinfo, off, static_cast<int>(fcap), ecap, edge_cap, node_cap, rank, node, relabel_table,

@@ -63,6 +63,16 @@ def views_like(flat, layout):
 
 
 class SageTrainEngine:
+    """See the module docstring.  Two execution modes, same arithmetic:
+
+    * `step(seeds, counter)` — everything on the current stream, one batch at a time;
+    * pipelined — the sampler of batch i+1 runs on a side stream into the other of two
+      sample-buffer slots while batch i computes (sampling needs no weights, and its ~20 short
+      latency-bound kernels hide completely behind the MFMA-bound GEMMs).  Driven eagerly with
+      `prefetch()` + `pipelined_step()`, or replayed from HIP graphs with `capture()` +
+      `replay()`.
+    """
+
     def __init__(self, model, sampler, features, labels, batch_size, lr=1e-3, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=0.0, world_size=1, process_group=None):
         if model.aggregator not in _REDUCE:
@@ -92,11 +102,13 @@ class SageTrainEngine:
         # the engine owns its sampler state (relabel table, stamps, buffers): a replayed graph
         # advances the stamp on the device, so the table cannot be shared with eager callers
         self.table = ops.new_relabel_table(self.graph.num_nodes, dev)
-        self.buf = ops.SampleBuffers(self.graph.num_nodes, self.hop_cap[-1], edge_cap, dev)
+        self.bufs = [ops.SampleBuffers(self.graph.num_nodes, self.hop_cap[-1], edge_cap, dev)
+                     for _ in range(2)]
         self.ctrl = torch.zeros(ops.CTRL_WORDS, dtype=torch.int64, device=dev)
         self._stamp = 0
-        st = self.buf.state
-        self.n_dev = [st[ops.ST_HOP_NODES + h: ops.ST_HOP_NODES + h + 1] for h in range(self.L + 1)]
+        # device-side row counts per slot: n_dev[slot][h] = #nodes after hop h
+        self.n_dev = [[b.state[ops.ST_HOP_NODES + h: ops.ST_HOP_NODES + h + 1] for h in range(self.L + 1)]
+                      for b in self.bufs]
 
         self.flat, self.layout = flatten_parameters(model)
         self.grad = torch.zeros_like(self.flat)
@@ -114,7 +126,7 @@ class SageTrainEngine:
             t_cap = self.hop_cap[self.L - 1 - i]
             fin = layer.lin_l.weight.size(1)
             fout = layer.lin_l.weight.size(0)
-            a = dict(t_cap=t_cap, fin=fin, fout=fout, t_dev=self.n_dev[self.L - 1 - i],
+            a = dict(t_cap=t_cap, fin=fin, fout=fout, hop=self.L - 1 - i,
                      agg=padded(t_cap, fin), z=padded(t_cap, fout), y=padded(t_cap, fout),
                      inv=torch.zeros(t_cap, dtype=torch.float32, device=dev),
                      dz=padded(t_cap, fout))
@@ -125,14 +137,26 @@ class SageTrainEngine:
                 a['dagg'] = padded(t_cap, fin)
             self.act.append(a)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        # running sums of the sampler's state block over replayed steps (batch sizes; a non-zero
+        self.row_loss = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        # running sums of the sampler's state block over computed batches (batch sizes; a non-zero
         # ST_ERROR sum means some batch reported an error)
         self.state_sum = torch.zeros(ops.STATE_WORDS, dtype=torch.int64, device=dev)
         self.counter = 0
         self.graphs = None
+        # pipelining state
+        self.side = torch.cuda.Stream(device=dev)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]      # slot sampled
+        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]   # slot's compute finished
+        self.use = 0            # slot the next compute reads
+        self.primed = False
+
+    @property
+    def buf(self):
+        """Sample buffers of the batch computed last (slot 0 in the non-pipelined mode)."""
+        return self.bufs[self.last_slot] if hasattr(self, 'last_slot') else self.bufs[0]
 
     # ------------------------------------------------------------------ pieces
-    def sample(self, seeds, counter, ctrl=None):
+    def sample(self, seeds, counter, slot=0, ctrl=None):
         """Enqueue the sampler for the batch `seeds[offset : offset+B]` (offset from ctrl or 0)."""
         if ctrl is None:
             self._stamp += 1
@@ -140,43 +164,44 @@ class SageTrainEngine:
         else:
             stamp = 1          # the device control block carries the running stamp
         ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed, counter,
-                          self.table, stamp, self.buf, ctrl=ctrl, num_seeds=self.B)
+                          self.table, stamp, self.bufs[slot], ctrl=ctrl, num_seeds=self.B)
 
-    def gather_layer0(self):
-        a = self.act[0]
-        ops.gather_reduce_fwd(self.features, self.buf.seg_ptr, self.buf.src, a['t_cap'], self.reduce,
-                              node_map=self.buf.node, num_targets_dev=a['t_dev'], out=a['agg'],
+    def gather_layer0(self, slot=0):
+        a, buf = self.act[0], self.bufs[slot]
+        ops.gather_reduce_fwd(self.features, buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
+                              node_map=buf.node, num_targets_dev=self.n_dev[slot][a['hop']], out=a['agg'],
                               want_argmax=False)
 
-    def forward_backward(self, skip_gather0=False):
-        L, buf = self.L, self.buf
+    def forward_backward(self, slot=0, skip_gather0=False):
+        L, buf = self.L, self.bufs[slot]
+        self.last_slot = slot
+        self.state_sum.add_(buf.state)
         x, node_map = self.features, buf.node
         lib = ops
         for i, layer in enumerate(self.model.layers):
             a = self.act[i]
-            t_cap, t_dev = a['t_cap'], a['t_dev']
+            t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
             if i == 0:
                 if not skip_gather0:
-                    self.gather_layer0()
+                    self.gather_layer0(slot)
             else:
                 lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
                                       num_targets_dev=t_dev, out=a['agg'], want_argmax=False)
             lib.linear_concat_fwd(a['agg'], layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
                                   m_dev=t_dev, rows2=node_map, out=a['z'])
-            relu = i < L - 1
-            lib.l2norm_relu_fwd(a['z'], relu, m=t_cap, m_dev=t_dev, y=a['y'], h=a.get('h'), inv_norm=a['inv'])
+            if i < L - 1:
+                lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'])
             x, node_map = a.get('h'), None
+        # last layer: normalise + cross-entropy on the seed rows + gradient w.r.t. z, one kernel
         last = self.act[-1]
-        lib.softmax_xent(last['y'], self.labels, label_rows=buf.node, m=self.B, loss=self.loss,
-                         dlogits=last['dz'], checked=True)
-        # backward; `g` = gradient w.r.t. the layer's (normalised, ReLU'd) output
+        lib.logits_xent_fused(last['z'], self.labels, buf.node, self.B, last['y'], last['inv'], last['dz'],
+                              self.row_loss, self.loss)
         self.grad.zero_()
-        g = last['dz']
         for i in range(L - 1, -1, -1):
             a, layer = self.act[i], self.model.layers[i]
-            t_cap, t_dev = a['t_cap'], a['t_dev']
-            relu = i < L - 1
-            lib.l2norm_relu_bwd(g, a['y'], a['inv'], relu, m=t_cap, m_dev=t_dev, dz=a['dz'])
+            t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
+            if i < L - 1:   # g = gradient w.r.t. relu(normalize(z)), left in dh by layer i+1
+                lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'])
             x_in = self.features if i == 0 else self.act[i - 1]['h']
             rows = buf.node if i == 0 else None
             lib.linear_dweight(a['dz'], a['agg'], m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
@@ -188,7 +213,6 @@ class SageTrainEngine:
                 lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       num_targets_dev=t_dev)
-                g = prev['dh']
 
     def all_reduce(self):
         if self.world_size > 1:
@@ -199,68 +223,126 @@ class SageTrainEngine:
                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
                       grad_scale=1.0 / self.world_size)
 
+    # ------------------------------------------------------------------ one batch at a time
     def step(self, seeds, counter=None):
         """One eager training step on `seeds` (device int64[B]); returns the device loss tensor."""
         if self.graphs is not None:
             raise RuntimeError("engine was captured: use replay()")
+        if self.primed:
+            raise RuntimeError("a prefetched batch is pending: use pipelined_step()")
         if counter is None:
             counter = self.counter
             self.counter += 1
-        self.sample(seeds, counter)
-        self.forward_backward()
+        self.sample(seeds, counter, slot=0)
+        self.forward_backward(slot=0)
         self.all_reduce()
         self.optimizer_step()
         return self.loss
 
-    # ------------------------------------------------------------------ HIP graph replay
+    # ------------------------------------------------------------------ pipelined, eager
+    def prefetch(self, seeds, counter):
+        """Sample `seeds` on the side stream into the slot the next-but-one compute will read."""
+        slot = self.use if not self.primed else 1 - self.use
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.side):
+            self.side.wait_stream(main) if not self.primed else self.side.wait_event(self.consumed[slot])
+            self.sample(seeds, counter, slot=slot)
+            self.ready[slot].record(self.side)
+        seeds.record_stream(self.side)
+        self.primed = True
+
+    def pipelined_step(self, next_seeds=None, next_counter=None, before_gather=None, after_gather=None):
+        """Train on the prefetched batch while the sampler of the next one runs beside it."""
+        if not self.primed:
+            raise RuntimeError("pipelined_step() needs a prefetch() first")
+        p = self.use
+        if next_seeds is not None:
+            self.prefetch(next_seeds, next_counter)
+        main = torch.cuda.current_stream()
+        main.wait_event(self.ready[p])
+        if before_gather is not None:
+            before_gather()
+        self.gather_layer0(p)
+        if after_gather is not None:
+            after_gather()
+        self.forward_backward(slot=p, skip_gather0=True)
+        self.all_reduce()
+        self.optimizer_step()
+        self.consumed[p].record(main)
+        if next_seeds is None:
+            self.primed = False
+        else:
+            self.use = 1 - p
+        return self.loss
+
+    # ------------------------------------------------------------------ pipelined, HIP graphs
     def capture(self, seed_pool, counter0=0, counter_stride=1, split_gather=False):
-        """Capture the step into HIP graphs.  Batch b of the replay uses seeds
+        """Capture the pipelined step into HIP graphs.  Replay b uses seeds
         seed_pool[b*B:(b+1)*B] (wrapping at the end of the pool) and Philox counter
         counter0 + b*counter_stride, exactly what step(seed_pool[...], counter) would use.
 
-        Graph 1: sampler (+ layer-0 gather unless split_gather) ; graph 2: the rest of
-        forward/backward ; [eager RCCL all-reduce when world_size > 1] ; graph 3: Adam + control
-        block advance.  split_gather leaves the layer-0 gather outside the graphs so a caller can
-        bracket that one kernel with events (bench.py's roofline probe)."""
+        Per slot: graph S (sampler + control-block advance, replayed on the side stream) and
+        graph C (forward/backward); one graph A (Adam).  The RCCL all-reduce stays eager between
+        C and A.  split_gather leaves the layer-0 gather outside graph C so a caller can bracket
+        that one kernel with events (bench.py's roofline probe)."""
         if seed_pool.numel() < self.B:
             raise RuntimeError("seed pool smaller than one batch")
+        if self.primed:
+            raise RuntimeError("a prefetched batch is pending")
         self.seed_pool = seed_pool.contiguous()
         self.split_gather = split_gather
         pool_len = (self.seed_pool.numel() // self.B) * self.B
         self.ctrl.zero_()
-        # stamps already used eagerly stay below the captured sequence
-        self.ctrl[ops.CTRL_STAMP] = self._stamp
+        self.ctrl[ops.CTRL_STAMP] = self._stamp    # stamps already used eagerly stay below
         torch.cuda.synchronize()
-        stream = torch.cuda.Stream()
-        stream.wait_stream(torch.cuda.current_stream())
-        g1, g2, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.stream(stream):
-            with torch.cuda.graph(g1, stream=stream):
-                self.sample(self.seed_pool, counter0, ctrl=self.ctrl)
-                self.state_sum.add_(self.buf.state)
-                if not split_gather:
-                    self.gather_layer0()
-            with torch.cuda.graph(g2, stream=stream):
-                self.forward_backward(skip_gather0=True)
-            with torch.cuda.graph(g3, stream=stream):
+        cap = torch.cuda.Stream(device=self.dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        gs = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        gc = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        ga = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(cap):
+            for slot in (0, 1):
+                with torch.cuda.graph(gs[slot], stream=cap):
+                    self.sample(self.seed_pool, counter0, slot=slot, ctrl=self.ctrl)
+                    ops.ctrl_advance(self.ctrl, counter_stride, 1, self.B, pool_len)
+                with torch.cuda.graph(gc[slot], stream=cap):
+                    self.forward_backward(slot=slot, skip_gather0=split_gather)
+            with torch.cuda.graph(ga, stream=cap):
                 self.optimizer_step()
-                ops.ctrl_advance(self.ctrl, counter_stride, 1, self.B, pool_len)
-        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
-        self.graphs = (g1, g2, g3)
-        # capture does not execute: state_sum is still clean, ctrl still at the start
+        self.graphs = (gs, gc, ga)
+        self.use = 0
+        # prime: sample the first batch
+        with torch.cuda.stream(self.side):
+            self.side.wait_stream(torch.cuda.current_stream())
+            gs[0].replay()
+            self.ready[0].record(self.side)
+        self.primed = True
+        self._first_replay = True
         return self
 
     def replay(self, before_gather=None, after_gather=None):
-        g1, g2, g3 = self.graphs
-        g1.replay()
+        gs, gc, ga = self.graphs
+        p = self.use
+        main = torch.cuda.current_stream()
+        with torch.cuda.stream(self.side):            # next batch into the other slot
+            if not self._first_replay:
+                self.side.wait_event(self.consumed[1 - p])
+            gs[1 - p].replay()
+            self.ready[1 - p].record(self.side)
+        self._first_replay = False
+        main.wait_event(self.ready[p])
         if self.split_gather:
             if before_gather is not None:
                 before_gather()
-            self.gather_layer0()
+            self.gather_layer0(p)
             if after_gather is not None:
                 after_gather()
-        g2.replay()
+        gc[p].replay()
+        self.last_slot = p
         self.all_reduce()
-        g3.replay()
+        ga.replay()
+        self.consumed[p].record(main)
+        self.use = 1 - p
         return self.loss

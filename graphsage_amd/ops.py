@@ -479,6 +479,30 @@ def softmax_xent(logits, labels, label_rows=None, m=None, grad_scale=1.0, loss=N
     return loss, dlogits
 
 
+def logits_xent_fused(z, labels, label_rows, m, y, inv_norm, dz, row_loss, loss, grad_scale=1.0):
+    """normalize + cross-entropy + gradient w.r.t. z in one pass (last layer of the step).
+    All buffers are caller-provided (static-shape engine); label_rows must be in range."""
+    lib = _lib.load()
+    zp, ld_z = _mat(z, "z")
+    n = z.size(1)
+    m = int(m)
+    dp, ld_dz = _mat(dz, "dz")
+    yp, ld_y = (None, 0) if y is None else _mat(y, "y")
+    if z.size(0) < m or dz.size(0) < m or dz.size(1) != n or row_loss.numel() < m or m <= 0 or \
+            (y is not None and (y.size(0) < m or y.size(1) != n)) or \
+            (inv_norm is not None and inv_norm.numel() < m) or \
+            (label_rows is not None and label_rows.numel() < m) or \
+            (label_rows is None and labels.numel() < m):
+        raise RuntimeError("logits_xent_fused: bad buffers")
+    rc = lib.sage_logits_xent_fused(zp, ld_z, _vec(labels, torch.int64, "labels"),
+                                    _vec(label_rows, torch.int64, "label_rows", allow_none=True), m, n,
+                                    float(grad_scale), yp, ld_y,
+                                    _vec(inv_norm, torch.float32, "inv_norm", allow_none=True), dp, ld_dz,
+                                    _vec(row_loss, torch.float32, "row_loss"), _p(loss, torch.float32, "loss"),
+                                    _stream())
+    _lib.check(rc, "sage_logits_xent_fused")
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8,
               weight_decay=0.0, grad_scale=1.0):
     """torch.optim.Adam step on flat fp32 buffers; step_dev (int64[1]) is advanced on device."""

@@ -278,6 +278,15 @@ int sage_softmax_xent(const float* logits, sage_i64 ld_logits, const sage_i64* l
                       const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
                       float* loss, float* dlogits, sage_i64 ld_dlogits, void* stream);
 
+/* The three calls above fused for the LAST layer of the training step (everything is
+ * row-local): y = normalize(z), loss = mean CE(y, labels), dz = d loss / d z (through the
+ * soft-max and the normalisation).  row_loss[m] receives the per-row losses (workspace and
+ * diagnostic), loss[0] their mean (fixed-order reduction).  y / inv_norm may be NULL. */
+int sage_logits_xent_fused(const float* z, sage_i64 ld_z, const sage_i64* labels,
+                           const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
+                           float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                           float* row_loss /*[m]*/, float* loss /*[1]*/, void* stream);
+
 /* Adam (torch.optim.Adam defaults semantics, no amsgrad, L2 weight_decay added to the
  * gradient) on one flat parameter buffer.  step_dev: device int64 step counter,
  * incremented by the kernel (so a captured graph advances it on replay). */

@@ -71,6 +71,7 @@ def test_graph_replay_matches_eager_steps(dev, split):
         lb = graphed.replay().clone()
         assert torch.equal(eager.buf.node[:B], graphed.buf.node[:B])
         assert torch.equal(eager.buf.state, graphed.buf.state)
+        assert eager.buf is eager.bufs[0] and graphed.buf is graphed.bufs[s % 2]
         n, e = int(eager.buf.state[0]), int(eager.buf.state[1])
         assert torch.equal(eager.buf.node[:n], graphed.buf.node[:n])
         assert torch.equal(eager.buf.src[:e], graphed.buf.src[:e])
@@ -79,3 +80,36 @@ def test_graph_replay_matches_eager_steps(dev, split):
     assert int(graphed.state_sum[4]) == 0 and int(graphed.step_dev) == 8
     with pytest.raises(RuntimeError):
         graphed.step(pool[:B])
+
+
+def test_pipelined_eager_matches_serial_steps(dev):
+    """prefetch()/pipelined_step(): the sampler of step s+1 runs on a side stream during step s;
+    the batches and the training trajectory are those of serial step() calls."""
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = planted_partition(2000, 40000, 24, 5, seed=5)
+    B = 32
+    graph = device_graph(data)
+    torch.manual_seed(2)
+    model_a = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
+    model_b = copy.deepcopy(model_a)
+    mk = lambda m: SageTrainEngine(m, NeighborSampler(data, [4, 3], seed=9), graph.features(data),
+                                   graph.labels(data), B, lr=1e-2)
+    serial, piped = mk(model_a), mk(model_b)
+    pool = torch.randperm(2000, generator=torch.Generator().manual_seed(1))[:6 * B].to(dev)
+    piped.prefetch(pool[:B], 0)
+    for s in range(6):
+        la = serial.step(pool[s * B:(s + 1) * B], counter=s).clone()
+        nxt = pool[(s + 1) * B:(s + 2) * B] if s < 5 else None
+        lb = piped.pipelined_step(nxt, s + 1).clone()
+        n, e = int(serial.buf.state[0]), int(serial.buf.state[1])
+        assert torch.equal(serial.buf.state, piped.buf.state)
+        assert torch.equal(serial.buf.node[:n], piped.buf.node[:n])
+        assert torch.equal(serial.buf.src[:e], piped.buf.src[:e])
+        torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(piped.flat, serial.flat, rtol=1e-4, atol=1e-6)
+    assert torch.equal(serial.state_sum, piped.state_sum)
+    piped.step(pool[:B], counter=99)          # pipeline drained: serial stepping works again

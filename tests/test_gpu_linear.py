@@ -126,3 +126,31 @@ def test_softmax_xent_and_adam(dev):
         pr, mr, vr = sage_ref.adam_ref(pr, grad, mr, vr, t, 1e-3, weight_decay=0.01)
         torch.testing.assert_close(pk.cpu(), pr, rtol=1e-5, atol=1e-6)
     assert int(step) == 3
+
+
+def test_logits_xent_fused_matches_three_kernels(dev):
+    """normalize + CE + gradient w.r.t. z in one kernel == F.normalize -> F.cross_entropy -> autograd."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(3)
+    m, n, N = 300, 41, 2000
+    z = _rand((m, n), g)
+    z[5] = 0.0
+    labels = torch.randint(0, n, (N,), generator=g)
+    rows = torch.randint(0, N, (m,), generator=g)
+    zt = z.clone().requires_grad_(True)
+    y = F.normalize(zt, p=2.0, dim=-1)
+    loss = F.cross_entropy(y, labels[rows])
+    loss.backward()
+    yk = torch.empty(m, n, device=dev)
+    inv = torch.empty(m, device=dev)
+    dz = torch.empty(m, n, device=dev)
+    row_loss = torch.empty(m, device=dev)
+    lk = torch.empty(1, device=dev)
+    ops.logits_xent_fused(z.to(dev), labels.to(dev), rows.to(dev), m, yk, inv, dz, row_loss, lk)
+    torch.testing.assert_close(yk.cpu(), y.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(lk.cpu()[0], loss.detach(), rtol=1e-5, atol=1e-6)
+    keep = torch.ones(m, dtype=torch.bool)
+    keep[5] = False                               # the zero row: clamp branch, compared separately
+    torch.testing.assert_close(dz.cpu()[keep], zt.grad[keep], rtol=1e-4, atol=1e-7)
+    ref_rows = F.cross_entropy(y.detach(), labels[rows], reduction="none")
+    torch.testing.assert_close(row_loss.cpu(), ref_rows, rtol=1e-5, atol=1e-6)
