@@ -53,6 +53,13 @@ struct GemmArgs {
   int atomic_out;          // 1: atomicAdd into out (split-K / accumulate)
   int k_chunk;             // split-K: contraction elements per blockIdx.z (multiple of BK)
   float* colsum;           // optional: colsum[m] += sum_k A(m,k) (dbias), only blockIdx.y == 0
+  // batched mode (d-weight pair): seg[0] and seg[1] are two INDEPENDENT problems that share the
+  // A operand; blockIdx.y < ny0 works on problem 0 (out, n), the rest on problem 1 (out2, n2)
+  int batched;
+  int ny0;
+  int n2;
+  float* out2;
+  int64_t ld_out2;
 };
 
 // ---- global -> register staging of one operand tile ---------------------------------
@@ -183,8 +190,17 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   }
   const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
   if (m0 >= m_lim) return;
-  const int64_t n0 = static_cast<int64_t>(blockIdx.y) * BN;
-  const int64_t n_lim = g.n;
+  int prob = 0, by = blockIdx.y;
+  if (g.batched && by >= g.ny0) {
+    prob = 1;
+    by -= g.ny0;
+  }
+  const int64_t n0 = static_cast<int64_t>(by) * BN;
+  const int64_t n_lim = prob ? g.n2 : g.n;
+  float* const out_p = prob ? g.out2 : g.out;
+  const int64_t ld_out_p = prob ? g.ld_out2 : g.ld_out;
+  const int s_begin = g.batched ? prob : 0;
+  const int s_end = g.batched ? prob + 1 : g.nseg;
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -207,10 +223,10 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   TileLoader<A_KC, BM, VEC> la;
   TileLoader<B_KC, BN, VEC> lb;
 
-  for (int s = 0; s < g.nseg; ++s) {
+  for (int s = s_begin; s < s_end; ++s) {
     const Segment& sg = g.seg[s];
     int k_lim = sg.k;
-    if (s == 0 && g.k_dev != nullptr) {
+    if ((s == 0 || g.batched) && g.k_dev != nullptr) {
       const int64_t v = *g.k_dev;
       if (v < k_lim) k_lim = static_cast<int>(v);
     }
@@ -279,12 +295,12 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j) {
       const int64_t col = n0 + wn0 + j * 32 + l31;
       const int64_t row0 = m0 + wm0 + i * 32 + 4 * half;
-      float* base = g.out + row0 * g.ld_out + col;
+      float* base = out_p + row0 * ld_out_p + col;
       if (g.atomic_out) {  // block-uniform
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int r = (e & 3) + 8 * (e >> 2);
-          if (col < n_lim && row0 + r < m_lim) atomicAdd(base + r * g.ld_out, acc[i][j][e]);
+          if (col < n_lim && row0 + r < m_lim) atomicAdd(base + r * ld_out_p, acc[i][j][e]);
         }
       } else {
 #pragma unroll
@@ -292,7 +308,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
           const int r = (e & 3) + 8 * (e >> 2);
           float v = acc[i][j][e] + bv[j];
           if (relu) v = fmaxf(v, 0.f);
-          if (col < n_lim && row0 + r < m_lim) base[r * g.ld_out] = v;
+          if (col < n_lim && row0 + r < m_lim) base[r * ld_out_p] = v;
         }
       }
     }
@@ -320,6 +336,13 @@ int op_vec(const float* p, int64_t ld, int64_t width) {
 
 template <bool A_KC, bool B_KC, int VEC>
 int launch_gemm_vec(const GemmArgs& g, int splits, hipStream_t stream, const char* what) {
+  if (g.batched) {  // 64x128 tiles; y covers problem 0 then problem 1
+    dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)),
+              static_cast<unsigned>(g.ny0 + cdiv(g.n2, 128)), static_cast<unsigned>(splits));
+    gemm_kernel<A_KC, B_KC, 64, 128, VEC><<<grid, kThreads, 0, stream>>>(g);
+    SAGE_CHECK_LAUNCH(what);
+    return SAGE_OK;
+  }
   if (g.n > 64) {
     dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)), static_cast<unsigned>(cdiv(g.n, 128)),
               static_cast<unsigned>(splits));
@@ -411,13 +434,18 @@ __global__ void __launch_bounds__(kThreads) skinny_fwd_kernel(SkinnyArgs s) {
       }
     }
   }
-  float mine = 0.f;
+  // cross-lane sums through one LDS transpose per wave (NT x 64 partials, row stride 65 so both
+  // the column writes and the row reads are conflict-free) instead of NT shuffle reductions
+  __shared__ float tile[kThreads / 64][NT][65];
+  float (*mt)[65] = tile[threadIdx.x >> 6];
 #pragma unroll
-  for (int n = 0; n < NT; ++n) {
-    if (n < s.n) {
-      const float t = wave_sum64(acc[n]);
-      if (lane == n) mine = t;
-    }
+  for (int n = 0; n < NT; ++n) mt[n][lane] = acc[n];
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave's own LDS writes have landed
+  __builtin_amdgcn_wave_barrier();
+  float mine = 0.f;
+  if (lane < s.n) {
+#pragma unroll 16
+    for (int l = 0; l < 64; ++l) mine += mt[lane][l];
   }
   if (lane < s.n) {
     if (s.epilogue & SAGE_EPI_BIAS) mine += s.bias[lane];
@@ -643,11 +671,59 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   }
   // split the contraction so that the grid covers the chip about twice
   const int64_t tiles = cdiv(n, 64) * cdiv(k, k > 64 ? 128 : 64);
-  int64_t splits = cdiv(512, tiles);
+  int64_t splits = 512 / tiles;   // <= 2 workgroups per CU: a third one would run alone at the end
   const int64_t max_splits = cdiv(m, 4 * BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
   splits = cdiv(m, g.k_chunk);
   return launch_gemm<false, false>(g, static_cast<int>(splits), stream, "gemm_kernel(dweight)");
+}
+
+extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1,
+                                    sage_i64 ld_a1, const sage_i64* rows1, int k1, float* dw1,
+                                    sage_i64 ld_dw1, const float* a2, sage_i64 ld_a2,
+                                    const sage_i64* rows2, int k2, float* dw2, sage_i64 ld_dw2,
+                                    sage_i64 m, const sage_i64* m_dev, int n, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && k1 > 0 && k2 > 0 && ld_dout >= n && ld_a1 >= k1 && ld_a2 >= k2 &&
+                   ld_dw1 >= k1 && ld_dw2 >= k2,
+               SAGE_EINVAL, "sage_linear_dweight2: bad shape (m=%lld n=%d k1=%d k2=%d)", (long long)m,
+               n, k1, k2);
+  SAGE_REQUIRE(m < (1ll << 31), SAGE_ELIMIT, "sage_linear_dweight2: m too large");
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(dout && a1 && a2 && dw1 && dw2, SAGE_EINVAL, "sage_linear_dweight2: NULL pointer argument");
+  if (n <= 64 || k1 <= 64 || k2 <= 64) {  // skinny shapes: the single-problem paths are better
+    int rc = sage_linear_dweight(dout, ld_dout, a1, ld_a1, rows1, m, m_dev, n, k1, dw1, ld_dw1, nullptr, stream_);
+    if (rc != SAGE_OK) return rc;
+    return sage_linear_dweight(dout, ld_dout, a2, ld_a2, rows2, m, m_dev, n, k2, dw2, ld_dw2, nullptr, stream_);
+  }
+  GemmArgs g = {};
+  g.seg[0].a = {dout, ld_dout, nullptr, op_vec(dout, ld_dout, n)};
+  g.seg[0].b = {a1, ld_a1, rows1, op_vec(a1, ld_a1, k1)};
+  g.seg[0].k = static_cast<int>(m);
+  g.seg[1].a = g.seg[0].a;
+  g.seg[1].b = {a2, ld_a2, rows2, op_vec(a2, ld_a2, k2)};
+  g.seg[1].k = static_cast<int>(m);
+  g.nseg = 2;
+  g.batched = 1;
+  g.m = n;
+  g.k_dev = m_dev;
+  g.n = k1;
+  g.out = dw1;
+  g.ld_out = ld_dw1;
+  g.n2 = k2;
+  g.out2 = dw2;
+  g.ld_out2 = ld_dw2;
+  g.ny0 = static_cast<int>(cdiv(k1, 128));
+  g.atomic_out = 1;
+  // both problems in one grid: aim at <= 4 workgroups per CU
+  const int64_t tiles = cdiv(n, 64) * (cdiv(k1, 128) + cdiv(k2, 128));
+  int64_t splits = 1024 / tiles;
+  const int64_t max_splits = cdiv(m, 4 * BK);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
+  splits = cdiv(m, g.k_chunk);
+  return launch_gemm<false, false>(g, static_cast<int>(splits), stream, "gemm_kernel(dweight2)");
 }

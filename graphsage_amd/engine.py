@@ -204,8 +204,8 @@ class SageTrainEngine:
                 lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'])
             x_in = self.features if i == 0 else self.act[i - 1]['h']
             rows = buf.node if i == 0 else None
-            lib.linear_dweight(a['dz'], a['agg'], m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
-            lib.linear_dweight(a['dz'], x_in, m=t_cap, m_dev=t_dev, rows=rows, dw=self.gviews[layer.lin_r.weight])
+            lib.linear_dweight2(a['dz'], a['agg'], self.gviews[layer.lin_l.weight], x_in,
+                                self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
             if i > 0:
                 prev = self.act[i - 1]
                 prev['dh'].zero_()

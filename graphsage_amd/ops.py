@@ -399,6 +399,27 @@ def linear_dweight(dout, a, m=None, m_dev=None, rows=None, dw=None, dbias=None):
     return dw
 
 
+def linear_dweight2(dout, a1, dw1, a2, dw2, m=None, m_dev=None, rows1=None, rows2=None):
+    """dw1 += dout^T @ a1[rows1]; dw2 += dout^T @ a2[rows2] in one launch."""
+    lib = _lib.load()
+    dp, ld_dout = _mat(dout, "dout")
+    a1p, ld_a1 = _mat(a1, "a1")
+    a2p, ld_a2 = _mat(a2, "a2")
+    w1p, ld_dw1 = _mat(dw1, "dw1")
+    w2p, ld_dw2 = _mat(dw2, "dw2")
+    n, k1, k2 = dout.size(1), a1.size(1), a2.size(1)
+    if m is None:
+        m = dout.size(0)
+    m = int(m)
+    if dout.size(0) < m or (rows1 is None and a1.size(0) < m) or (rows2 is None and a2.size(0) < m) or \
+            dw1.shape != (n, k1) or dw2.shape != (n, k2):
+        raise RuntimeError("linear_dweight2: shape mismatch")
+    rc = lib.sage_linear_dweight2(dp, ld_dout, a1p, ld_a1, _rows(rows1, m, "rows1"), k1, w1p, ld_dw1,
+                                  a2p, ld_a2, _rows(rows2, m, "rows2"), k2, w2p, ld_dw2, m,
+                                  _count(m_dev, "m_dev"), n, _stream())
+    _lib.check(rc, "sage_linear_dweight2")
+
+
 # ------------------------------------------------------------------------------- rows
 def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None):
     """y = normalize(z); h = relu(y) if relu (reference layers/sage.py:131-132,

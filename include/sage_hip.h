@@ -229,6 +229,15 @@ int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const float* a, sag
                         const sage_i64* rows, sage_i64 m, const sage_i64* m_dev, int n, int k,
                         float* dw, sage_i64 ld_dw, float* dbias, void* stream);
 
+/* The layer's two weight gradients in one launch (they share dout and come in pairs: the
+ * backward of sage_linear_concat_fwd):  dw1 += dout^T @ a1[rows1],  dw2 += dout^T @ a2[rows2].
+ * One grid over both problems fills the chip more evenly than two launches. */
+int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1, sage_i64 ld_a1,
+                         const sage_i64* rows1, int k1, float* dw1, sage_i64 ld_dw1,
+                         const float* a2, sage_i64 ld_a2, const sage_i64* rows2, int k2,
+                         float* dw2, sage_i64 ld_dw2, sage_i64 m, const sage_i64* m_dev, int n,
+                         void* stream);
+
 /* ------------------------------------------------------------------------------------
  * (a-7) LSTM aggregator (layers/sage.py:67-69, :147-193): per target, the first n_in
  * neighbours' rows (padded by repeating the first, :164) are flattened to one vector (:179)

@@ -154,3 +154,22 @@ def test_logits_xent_fused_matches_three_kernels(dev):
     torch.testing.assert_close(dz.cpu()[keep], zt.grad[keep], rtol=1e-4, atol=1e-7)
     ref_rows = F.cross_entropy(y.detach(), labels[rows], reduction="none")
     torch.testing.assert_close(row_loss.cpu(), ref_rows, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("m,n,k1,k2", [(3000, 256, 602, 602), (700, 96, 130, 300), (512, 41, 256, 256)])
+def test_linear_dweight2(dev, m, n, k1, k2):
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m)
+    dout, a1, table = _rand((m, n), g), _rand((m, k1), g), _rand((2 * m, k2), g)
+    rows = torch.randint(0, 2 * m, (m,), generator=g)
+    ld = (k2 + 15) // 16 * 16
+    tpad = torch.zeros((2 * m, ld), device=dev)
+    tpad[:, :k2] = table.to(dev)
+    dw1 = torch.zeros(n, k1, device=dev)
+    dw2 = torch.zeros(n, k2, device=dev)
+    mdev = torch.tensor([m - 37], device=dev)
+    ops.linear_dweight2(dout.to(dev), a1.to(dev), dw1, tpad[:, :k2], dw2, m=m, m_dev=mdev, rows2=rows.to(dev))
+    h = m - 37
+    tol = 2e-4 * max(1.0, (m / 100) ** 0.5)
+    torch.testing.assert_close(dw1.cpu(), dout[:h].t() @ a1[:h], rtol=RTOL, atol=tol)
+    torch.testing.assert_close(dw2.cpu(), dout[:h].t() @ table[rows[:h]], rtol=RTOL, atol=tol)
