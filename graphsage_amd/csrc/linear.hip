@@ -377,6 +377,11 @@ int launch_gemm(const GemmArgs& g, int splits, hipStream_t stream, const char* w
 // round trip, so these run as plain VALU kernels with one wave per row instead: the whole
 // weight matrix (<= 64 rows) stays in L1/L2 and every lane streams 16-byte vectors.
 // ======================================================================================
+__global__ void zero_rows_kernel(float* out, int64_t ld, int64_t m, int n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < m * n) out[(i / n) * ld + (i % n)] = 0.f;
+}
+
 struct SkinnyArgs {
   Segment seg[2];
   int nseg;
@@ -402,56 +407,6 @@ __device__ inline float4 load4_guard(const float* p, int k0, int k_lim) {
   if (k0 + 2 >= k_lim) v.z = 0.f;
   if (k0 + 3 >= k_lim) v.w = 0.f;
   return v;
-}
-
-// out[m][n] = sum_seg sum_k a[rows(m)][k] * w[n][k]  (n <= NT <= 64): one wave per row m
-template <int NT>
-__global__ void __launch_bounds__(kThreads) skinny_fwd_kernel(SkinnyArgs s) {
-  int64_t m_lim = s.m;
-  if (s.m_dev != nullptr) {
-    const int64_t v = *s.m_dev;
-    if (v < m_lim) m_lim = v;
-  }
-  const int lane = threadIdx.x & 63;
-  const int64_t m = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6);
-  if (m >= m_lim) return;
-  float acc[NT];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) acc[n] = 0.f;
-  for (int sg = 0; sg < s.nseg; ++sg) {
-    const Segment& g = s.seg[sg];
-    const int64_t r = g.a.rowmap != nullptr ? g.a.rowmap[m] : m;
-    const float* arow = g.a.p + r * g.a.ld;
-    for (int k0 = lane * 4; k0 < g.k; k0 += 256) {
-      const float4 av = load4_guard(arow, k0, g.k);
-      // branch-free over n (rows beyond s.n re-read the last row and are discarded) so that the
-      // NT independent weight loads are issued back to back instead of one round trip each
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int nc = n < s.n ? n : s.n - 1;
-        const float4 wv = load4_guard(g.b.p + nc * g.b.ld, k0, g.k);
-        acc[n] += av.x * wv.x + av.y * wv.y + av.z * wv.z + av.w * wv.w;
-      }
-    }
-  }
-  // cross-lane sums through one LDS transpose per wave (NT x 64 partials, row stride 65 so both
-  // the column writes and the row reads are conflict-free) instead of NT shuffle reductions
-  __shared__ float tile[kThreads / 64][NT][65];
-  float (*mt)[65] = tile[threadIdx.x >> 6];
-#pragma unroll
-  for (int n = 0; n < NT; ++n) mt[n][lane] = acc[n];
-  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): the wave's own LDS writes have landed
-  __builtin_amdgcn_wave_barrier();
-  float mine = 0.f;
-  if (lane < s.n) {
-#pragma unroll 16
-    for (int l = 0; l < 64; ++l) mine += mt[lane][l];
-  }
-  if (lane < s.n) {
-    if (s.epilogue & SAGE_EPI_BIAS) mine += s.bias[lane];
-    if (s.epilogue & SAGE_EPI_RELU) mine = fmaxf(mine, 0.f);
-    s.out[m * s.ld_out + lane] = mine;
-  }
 }
 
 // da[m][k] (+)= sum_n dout[m][n] * w[n][k]  (n <= 64): one wave per row m, lanes over k
@@ -538,13 +493,6 @@ skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, const flo
   }
 }
 
-template <int NT>
-int launch_skinny_fwd(const SkinnyArgs& s, hipStream_t stream) {
-  skinny_fwd_kernel<NT><<<static_cast<unsigned>(cdiv(s.m, kThreads / 64)), kThreads, 0, stream>>>(s);
-  SAGE_CHECK_LAUNCH("skinny_fwd_kernel");
-  return SAGE_OK;
-}
-
 }  // namespace
 }  // namespace sage
 
@@ -584,19 +532,20 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
   g.ld_out = ld_out;
   g.bias = bias;
   g.epilogue = epilogue;
-  bool all4 = true;
-  for (int s = 0; s < g.nseg; ++s) all4 = all4 && g.seg[s].a.vec == 4 && g.seg[s].b.vec == 4;
-  if (n <= 64 && all4) {
-    SkinnyArgs s = {};
-    s.seg[0] = g.seg[0];
-    s.seg[1] = g.seg[1];
-    s.nseg = g.nseg;
-    s.m = m; s.m_dev = m_dev; s.n = n; s.out = out; s.ld_out = ld_out; s.bias = bias; s.epilogue = epilogue;
-    if (n <= 8) return launch_skinny_fwd<8>(s, stream);
-    if (n <= 16) return launch_skinny_fwd<16>(s, stream);
-    if (n <= 32) return launch_skinny_fwd<32>(s, stream);
-    if (n <= 48) return launch_skinny_fwd<48>(s, stream);
-    return launch_skinny_fwd<64>(s, stream);
+  // Few output tiles (the class-logit layer: M = 512, N = 41): split the contraction over
+  // blockIdx.z so that more than M/64 workgroups share the latency-bound K-steps; the partial
+  // sums are combined with fp32 atomics into a zeroed output.
+  const int64_t tiles = cdiv(m, 64) * cdiv(n, n > 64 ? 128 : 64);
+  const int kmax = k1 > k2 ? k1 : k2;
+  if (epilogue == SAGE_EPI_NONE && tiles <= 32 && kmax >= 4 * BK) {
+    int splits = kmax / (2 * BK);
+    if (splits > 8) splits = 8;
+    g.k_chunk = static_cast<int>(cdiv(cdiv(kmax, splits), BK) * BK);
+    splits = static_cast<int>(cdiv(kmax, g.k_chunk));
+    g.atomic_out = 1;
+    zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
+    SAGE_CHECK_LAUNCH("zero_rows_kernel");
+    return launch_gemm<true, true>(g, splits, stream, "gemm_kernel(fwd, split-K)");
   }
   return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");
 }
