@@ -74,7 +74,7 @@ class SageTrainEngine:
     """
 
     def __init__(self, model, sampler, features, labels, batch_size, lr=1e-3, betas=(0.9, 0.999),
-                 eps=1e-8, weight_decay=0.0, world_size=1, process_group=None):
+                 eps=1e-8, weight_decay=0.0, world_size=1, process_group=None, overlap_gather=False):
         if model.aggregator not in _REDUCE:
             raise NotImplementedError(f"engine supports {sorted(_REDUCE)}, got {model.aggregator}")
         self.model = model
@@ -136,6 +136,11 @@ class SageTrainEngine:
             if i > 0:
                 a['dagg'] = padded(t_cap, fin)
             self.act.append(a)
+        # layer-0 aggregate per sample slot: with overlap_gather the HBM-bound gather of batch i+1
+        # runs on the side stream (it needs no weights) beside the MFMA-bound backward of batch i
+        self.overlap_gather = bool(overlap_gather)
+        self.agg0 = [self.act[0]['agg'],
+                     padded(self.act[0]['t_cap'], self.act[0]['fin']) if overlap_gather else self.act[0]['agg']]
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.row_loss = torch.zeros(self.B, dtype=torch.float32, device=dev)
         # running sums of the sampler's state block over computed batches (batch sizes; a non-zero
@@ -169,10 +174,16 @@ class SageTrainEngine:
     def gather_layer0(self, slot=0):
         a, buf = self.act[0], self.bufs[slot]
         ops.gather_reduce_fwd(self.features, buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
-                              node_map=buf.node, num_targets_dev=self.n_dev[slot][a['hop']], out=a['agg'],
-                              want_argmax=False)
+                              node_map=buf.node, num_targets_dev=self.n_dev[slot][a['hop']],
+                              out=self.agg0[slot], want_argmax=False)
 
     def forward_backward(self, slot=0, skip_gather0=False):
+        self.forward(slot, skip_gather0)
+        self.backward(slot)
+
+    def forward(self, slot=0, skip_gather0=False):
+        """Layers + normalised logits + per-row cross entropy (and dz of the last layer, which
+        the fused kernel produces in the same pass)."""
         L, buf = self.L, self.bufs[slot]
         self.last_slot = slot
         self.state_sum.add_(buf.state)
@@ -181,13 +192,14 @@ class SageTrainEngine:
         for i, layer in enumerate(self.model.layers):
             a = self.act[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
+            agg = self.agg0[slot] if i == 0 else a['agg']
             if i == 0:
                 if not skip_gather0:
                     self.gather_layer0(slot)
             else:
                 lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
-                                      num_targets_dev=t_dev, out=a['agg'], want_argmax=False)
-            lib.linear_concat_fwd(a['agg'], layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
+                                      num_targets_dev=t_dev, out=agg, want_argmax=False)
+            lib.linear_concat_fwd(agg, layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
                                   m_dev=t_dev, rows2=node_map, out=a['z'])
             if i < L - 1:
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'])
@@ -196,7 +208,14 @@ class SageTrainEngine:
         last = self.act[-1]
         lib.logits_xent_fused(last['z'], self.labels, buf.node, self.B, last['y'], last['inv'], last['dz'],
                               self.row_loss, self.loss)
+
+    def backward(self, slot=0):
+        L, buf = self.L, self.bufs[slot]
+        lib = ops
         self.grad.zero_()
+        # (the upper layers' weight gradients are leaves of the dependency chain, but forking
+        # them onto another stream costs more in cross-queue waits than the ~20 us it hides:
+        # measured 0.41 -> 0.45 ms/step on MI355X / ROCm 7.2, so everything stays on one stream)
         for i in range(L - 1, -1, -1):
             a, layer = self.act[i], self.model.layers[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
@@ -204,8 +223,8 @@ class SageTrainEngine:
                 lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'])
             x_in = self.features if i == 0 else self.act[i - 1]['h']
             rows = buf.node if i == 0 else None
-            lib.linear_dweight2(a['dz'], a['agg'], self.gviews[layer.lin_l.weight], x_in,
-                                self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
+            lib.linear_dweight2(a['dz'], self.agg0[slot] if i == 0 else a['agg'], self.gviews[layer.lin_l.weight],
+                                x_in, self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
             if i > 0:
                 prev = self.act[i - 1]
                 prev['dh'].zero_()
@@ -240,13 +259,20 @@ class SageTrainEngine:
         return self.loss
 
     # ------------------------------------------------------------------ pipelined, eager
-    def prefetch(self, seeds, counter):
-        """Sample `seeds` on the side stream into the slot the next-but-one compute will read."""
+    def prefetch(self, seeds, counter, before_gather=None, after_gather=None):
+        """Sample `seeds` on the side stream into the slot the next-but-one compute will read
+        (and, with overlap_gather, run that batch's layer-0 gather there too)."""
         slot = self.use if not self.primed else 1 - self.use
         main = torch.cuda.current_stream()
         with torch.cuda.stream(self.side):
             self.side.wait_stream(main) if not self.primed else self.side.wait_event(self.consumed[slot])
             self.sample(seeds, counter, slot=slot)
+            if self.overlap_gather:
+                if before_gather is not None:
+                    before_gather()
+                self.gather_layer0(slot)
+                if after_gather is not None:
+                    after_gather()
             self.ready[slot].record(self.side)
         seeds.record_stream(self.side)
         self.primed = True
@@ -256,15 +282,17 @@ class SageTrainEngine:
         if not self.primed:
             raise RuntimeError("pipelined_step() needs a prefetch() first")
         p = self.use
+        ov = self.overlap_gather
         if next_seeds is not None:
-            self.prefetch(next_seeds, next_counter)
+            self.prefetch(next_seeds, next_counter, before_gather if ov else None, after_gather if ov else None)
         main = torch.cuda.current_stream()
         main.wait_event(self.ready[p])
-        if before_gather is not None:
-            before_gather()
-        self.gather_layer0(p)
-        if after_gather is not None:
-            after_gather()
+        if not ov:
+            if before_gather is not None:
+                before_gather()
+            self.gather_layer0(p)
+            if after_gather is not None:
+                after_gather()
         self.forward_backward(slot=p, skip_gather0=True)
         self.all_reduce()
         self.optimizer_step()
@@ -274,6 +302,53 @@ class SageTrainEngine:
         else:
             self.use = 1 - p
         return self.loss
+
+    # ------------------------------------------------------------------ epochs and evaluation
+    def train_epoch(self, seeds, epoch=0, rank=0):
+        """One pass over `seeds` (device int64) in batches of B with the pipelined step (the
+        tail that does not fill a batch is dropped, as under data parallelism every rank must
+        run the same number of steps).  The loss is accumulated on the device — the reference
+        synchronises every step with loss.item() (trainers/node_level_graphsage_trainers.py:46)
+        — and returned as a device tensor: mean training loss over the epoch."""
+        from .dist import batch_counter
+        nb = seeds.numel() // self.B
+        if nb == 0:
+            raise RuntimeError("fewer seeds than one batch")
+        total = torch.zeros(1, dtype=torch.float32, device=self.dev)
+
+        def counter(b):
+            return batch_counter(epoch, nb, b, rank, self.world_size)
+        self.prefetch(seeds[:self.B], counter(0))
+        for b in range(nb):
+            nxt = seeds[(b + 1) * self.B:(b + 2) * self.B] if b + 1 < nb else None
+            loss = self.pipelined_step(nxt, counter(b + 1) if nxt is not None else None)
+            total += loss
+        return total / nb
+
+    @torch.no_grad()
+    def evaluate(self, seeds, counter0=1 << 40):
+        """Forward-only pass over `seeds` (any length): returns (correct, count) as device int64
+        tensors — accuracy = micro-F1 for single-label classification (what
+        f1_score(average='micro') returns in trainers/node_level_graphsage_trainers.py:56-57).
+        Sampled fan-out neighbourhoods as in GraphSAGE.inference (models/graphsage.py:51-68)."""
+        if self.primed:
+            raise RuntimeError("a prefetched batch is pending")
+        B = self.B
+        n = seeds.numel()
+        correct = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        last = self.act[-1]
+        rows = torch.arange(B, device=self.dev)
+        for b in range((n + B - 1) // B):
+            chunk = seeds[b * B:(b + 1) * B]
+            valid = chunk.numel()
+            if valid < B:      # pad the tail with its first seed; padded rows are masked below
+                chunk = torch.cat([chunk, chunk[:1].expand(B - valid)])
+            self.sample(chunk.contiguous(), counter0 + b, slot=0)
+            self.forward(slot=0)
+            pred = last['y'][:B].argmax(dim=1)
+            hit = (pred == self.labels[chunk]) & (rows < valid)
+            correct += hit.sum()
+        return correct, torch.full((1,), n, dtype=torch.int64, device=self.dev)
 
     # ------------------------------------------------------------------ pipelined, HIP graphs
     def capture(self, seed_pool, counter0=0, counter_stride=1, split_gather=False):
@@ -305,8 +380,10 @@ class SageTrainEngine:
                 with torch.cuda.graph(gs[slot], stream=cap):
                     self.sample(self.seed_pool, counter0, slot=slot, ctrl=self.ctrl)
                     ops.ctrl_advance(self.ctrl, counter_stride, 1, self.B, pool_len)
+                    if self.overlap_gather and not split_gather:
+                        self.gather_layer0(slot)
                 with torch.cuda.graph(gc[slot], stream=cap):
-                    self.forward_backward(slot=slot, skip_gather0=split_gather)
+                    self.forward_backward(slot=slot, skip_gather0=split_gather or self.overlap_gather)
             with torch.cuda.graph(ga, stream=cap):
                 self.optimizer_step()
         torch.cuda.current_stream().wait_stream(cap)
@@ -317,6 +394,8 @@ class SageTrainEngine:
         with torch.cuda.stream(self.side):
             self.side.wait_stream(torch.cuda.current_stream())
             gs[0].replay()
+            if self.overlap_gather and split_gather:
+                self.gather_layer0(0)
             self.ready[0].record(self.side)
         self.primed = True
         self._first_replay = True
@@ -330,10 +409,16 @@ class SageTrainEngine:
             if not self._first_replay:
                 self.side.wait_event(self.consumed[1 - p])
             gs[1 - p].replay()
+            if self.overlap_gather and self.split_gather:
+                if before_gather is not None:
+                    before_gather()
+                self.gather_layer0(1 - p)
+                if after_gather is not None:
+                    after_gather()
             self.ready[1 - p].record(self.side)
         self._first_replay = False
         main.wait_event(self.ready[p])
-        if self.split_gather:
+        if self.split_gather and not self.overlap_gather:
             if before_gather is not None:
                 before_gather()
             self.gather_layer0(p)

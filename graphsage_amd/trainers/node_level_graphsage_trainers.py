@@ -1,0 +1,150 @@
+"""Node-level GraphSAGE trainers (reference graphsage/trainers/node_level_graphsage_trainers.py).
+
+SupervisedGraphSageTrainerForNodeLevelTask.train is the reference's step (:34-47): forward on
+the sampled batch, loss_fn on the seed rows PLUS the unsupervised term (two more forwards),
+backward, optimizer step.  Differences: the loss is accumulated on the device (one sync per
+epoch instead of loss.item() per step, :46); micro-F1 is computed on the device — for
+single-label predictions f1_score(average='micro') equals accuracy, which is what :56-57 compute
+twice.  With `supervised_only=True` (fig2a's step definition, experiments/fig2a/runners/
+graphsage_runners.py:38-46) and a mean/sum model trained with cross entropy + Adam, the epoch runs
+on the static-shape engine (graphsage_amd/engine.py).
+
+The unsupervised trainer's downstream classifier is sklearn's SGDClassifier in the reference
+(:122-125); sklearn baselines are out of scope (§8), so test() here fits a logistic-regression
+head on the device with the same role and reports the same keys.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import settings
+from .base_trainers import GraphSageBaseTrainer, SupervisedGraphSageBaseTrainer, dataloader_kwargs
+
+
+def _micro_f1(y_hat, y):
+    """accuracy == micro-averaged F1 for single-label multi-class predictions."""
+    acc = (y_hat == y).sum().float() / max(int(y.numel()), 1)
+    return acc
+
+
+class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer):
+    def __init__(self, data, loader, *args, supervised_only=False, use_engine=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.data = data
+        self.supervised_only = supervised_only
+        mk = lambda mask: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
+                                 **dataloader_kwargs)
+        self.train_loader = mk(data.train_mask)
+        self.val_loader = mk(data.val_mask)
+        self.test_loader = mk(data.test_mask)
+        self.engine = None
+        if use_engine is None:
+            use_engine = supervised_only
+        if use_engine:
+            self.engine = self._make_engine()
+
+    def _make_engine(self):
+        from ..engine import SageTrainEngine
+        if not self.supervised_only:
+            raise RuntimeError("the engine runs the supervised term only (supervised_only=True)")
+        if not isinstance(self.optimizer, torch.optim.Adam):
+            raise RuntimeError("the engine implements Adam")
+        g = self.optimizer.param_groups[0]
+        sampler = self.train_loader.neighbor_sampler
+        graph = sampler.graph
+        return SageTrainEngine(self.model, sampler, graph.features(self.data), graph.labels(self.data),
+                               self.train_loader.batch_size, lr=g['lr'], betas=g['betas'], eps=g['eps'],
+                               weight_decay=g['weight_decay'])
+
+    def train(self, epoch):
+        self.model.train()
+        if self.engine is not None:
+            seeds = self.train_loader._idx_dev
+            return self.engine.train_epoch(seeds, epoch=epoch)
+        total = torch.zeros((), device=self.device)
+        count = 0
+        for batch in self.train_loader:
+            batch = batch.to(self.device)
+            self.optimizer.zero_grad()
+            y = batch.y[:batch.batch_size]
+            y_hat = self.model(batch.x, batch.edge_index)[:batch.batch_size]
+            loss = self.loss_fn(y_hat, y)
+            if not self.supervised_only:
+                loss = loss + self.unsup_loss_fn(y_hat, batch, self.data)
+            loss.backward()
+            self.optimizer.step()
+            total += loss.detach() * batch.batch_size
+            count += batch.batch_size
+        return total / count
+
+    @torch.no_grad()
+    def eval(self, loader):
+        y_hat = self.model.inference(loader).argmax(dim=-1)
+        y = torch.cat([batch.y[:batch.batch_size] for batch in loader]).to(y_hat.device)
+        acc = float(_micro_f1(y_hat, y))
+        return acc, acc
+
+    @torch.no_grad()
+    def test(self):
+        train_acc, train_f1 = self.eval(self.train_loader) if not settings.NO_EVAL_TRAIN else (None, None)
+        val_acc, val_f1 = self.eval(self.val_loader)
+        test_acc, test_f1 = self.eval(self.test_loader)
+        return {'train_acc': train_acc, 'train_f1': train_f1, 'val_acc': val_acc, 'val_f1': val_f1,
+                'test_acc': test_acc, 'test_f1': test_f1}
+
+
+class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
+    def __init__(self, data, loader, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.data = data
+        mk = lambda mask: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
+                                 **dataloader_kwargs)
+        self.train_loader = mk(data.train_mask)
+        self.val_loader = mk(data.val_mask)
+        self.test_loader = mk(data.test_mask)
+
+    def train(self, epoch):
+        self.model.train()
+        total = torch.zeros((), device=self.device)
+        count = 0
+        for batch in self.train_loader:
+            batch = batch.to(self.device)
+            self.optimizer.zero_grad()
+            out = self.model(batch.x, batch.edge_index)[:batch.batch_size]
+            loss = self.unsup_loss_fn(out, batch, self.data)
+            loss.backward()
+            self.optimizer.step()
+            total += loss.detach() * out.size(0)
+            count += batch.batch_size
+        return total / count
+
+    def _fit_head(self, x, y, num_classes, epochs=200, lr=0.5):
+        """Multinomial logistic regression on frozen embeddings (role of the reference's
+        SGDClassifier(loss='log'), :122-125), full-batch on the device."""
+        w = torch.zeros(x.size(1), num_classes, device=x.device, requires_grad=True)
+        b = torch.zeros(num_classes, device=x.device, requires_grad=True)
+        opt = torch.optim.Adam([w, b], lr=lr)
+        with torch.enable_grad():
+            for _ in range(epochs):
+                opt.zero_grad()
+                F.cross_entropy(x @ w + b, y).backward()
+                opt.step()
+        return w.detach(), b.detach()
+
+    @torch.no_grad()
+    def test(self):
+        y_all = self.data.y.to(self.device)
+        masks = {k: getattr(self.data, f'{k}_mask').to(self.device) for k in ('train', 'val', 'test')}
+        outs = {'train': self.model.inference(self.train_loader)}
+        num_classes = int(y_all.max()) + 1
+        w, b = self._fit_head(outs['train'], y_all[masks['train']], num_classes)
+        outs['val'] = self.model.inference(self.val_loader)
+        outs['test'] = self.model.inference(self.test_loader)
+        res = {}
+        for k in ('train', 'val', 'test'):
+            if k == 'train' and settings.NO_EVAL_TRAIN:
+                res['train_acc'] = res['train_f1'] = None
+                continue
+            pred = (outs[k] @ w + b).argmax(-1)
+            acc = float(_micro_f1(pred, y_all[masks[k]]))
+            res[f'{k}_acc'] = res[f'{k}_f1'] = acc
+        return res

@@ -8,8 +8,8 @@ ld = 608
 table = torch.randn(NT, ld, device=dev)[:, :K]
 agg = torch.randn(13312, ld, device=dev)[:, :K]
 rows = torch.randint(0, NT, (13312,), device=dev)
-wl = torch.randn(N, ld, device=dev)[:, :K] * K ** -0.5
-wr = torch.randn(N, ld, device=dev)[:, :K] * K ** -0.5
+wl = torch.randn(N, ld, device=dev).mul_(K ** -0.5)[:, :K]
+wr = torch.randn(N, ld, device=dev).mul_(K ** -0.5)[:, :K]
 out = torch.empty(13312, N, device=dev)
 mdev = torch.tensor([M], device=dev)
 dz = torch.randn(13312, N, device=dev)

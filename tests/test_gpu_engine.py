@@ -43,8 +43,9 @@ def test_engine_matches_module_path(dev, aggregator):
     assert int(engine.step_dev) == 4
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("split", [False, True])
-def test_graph_replay_matches_eager_steps(dev, split):
+def test_graph_replay_matches_eager_steps(dev, split, overlap):
     """HIP-graph replay (device control block drives seeds / Philox counter / stamp) runs the
     same steps as eager engine.step, including the wrap at the end of the seed pool."""
     from graphsage_amd.datasets import planted_partition
@@ -58,9 +59,9 @@ def test_graph_replay_matches_eager_steps(dev, split):
     torch.manual_seed(1)
     model_a = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
     model_b = copy.deepcopy(model_a)
-    mk = lambda m: SageTrainEngine(m, NeighborSampler(data, [4, 3], seed=9), graph.features(data),
-                                   graph.labels(data), B, lr=1e-2)
-    eager, graphed = mk(model_a), mk(model_b)
+    mk = lambda m, ov=False: SageTrainEngine(m, NeighborSampler(data, [4, 3], seed=9), graph.features(data),
+                                             graph.labels(data), B, lr=1e-2, overlap_gather=ov)
+    eager, graphed = mk(model_a), mk(model_b, overlap)
     pool = torch.randperm(2000, generator=torch.Generator().manual_seed(0))[:3 * B + 7].to(dev)  # 3 batches
     graphed.step(pool[:B], counter=1000)      # an eager step before capture (stamps already in use)
     eager.step(pool[:B], counter=1000)
@@ -82,7 +83,8 @@ def test_graph_replay_matches_eager_steps(dev, split):
         graphed.step(pool[:B])
 
 
-def test_pipelined_eager_matches_serial_steps(dev):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_pipelined_eager_matches_serial_steps(dev, overlap):
     """prefetch()/pipelined_step(): the sampler of step s+1 runs on a side stream during step s;
     the batches and the training trajectory are those of serial step() calls."""
     from graphsage_amd.datasets import planted_partition
@@ -96,9 +98,9 @@ def test_pipelined_eager_matches_serial_steps(dev):
     torch.manual_seed(2)
     model_a = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
     model_b = copy.deepcopy(model_a)
-    mk = lambda m: SageTrainEngine(m, NeighborSampler(data, [4, 3], seed=9), graph.features(data),
-                                   graph.labels(data), B, lr=1e-2)
-    serial, piped = mk(model_a), mk(model_b)
+    mk = lambda m, ov=False: SageTrainEngine(m, NeighborSampler(data, [4, 3], seed=9), graph.features(data),
+                                             graph.labels(data), B, lr=1e-2, overlap_gather=ov)
+    serial, piped = mk(model_a), mk(model_b, overlap)
     pool = torch.randperm(2000, generator=torch.Generator().manual_seed(1))[:6 * B].to(dev)
     piped.prefetch(pool[:B], 0)
     for s in range(6):

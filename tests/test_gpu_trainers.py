@@ -1,0 +1,167 @@
+"""f-1 / f-4: trainer loop, evaluation and the fig2a harness on the device (SURVEY §8c end-to-end
+KATs: same init + same sampled batches => same loss curve as the CPU oracle for 20 steps;
+micro-F1 on a planted-partition graph within 0.5 pt of the oracle-trained model)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import csc, sage_ref, sampler
+from tests.helpers import load_layers, make_layers
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(n=1500, e=30000, f=24, c=5, seed=3, noise=1.5):
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.datasets.synthetic import SyntheticDataset, _masks
+    d = planted_partition(n, e, f, c, homophily=0.85, noise=noise, seed=seed)
+    _masks(d, 640, 200, 400, seed)
+    return SyntheticDataset([d], c)
+
+
+def _oracle_train(data, layers, seeds_batches, fanout, rng_seed, counters, lr, B):
+    """fig2a step on the CPU oracle: returns the loss curve and the trained layers."""
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), data.num_nodes)
+    params = [{k: v.clone() for k, v in p.items()} for p in layers]
+    state = [{k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()} for p in params]
+    losses = []
+    for step, (seeds, counter) in enumerate(zip(seeds_batches, counters), start=1):
+        node, src, dst, _, _, _ = sampler.neighbor_sample(c0, r0, seeds.numpy(), fanout, rng_seed, counter)
+        leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+        loss, _ = sage_ref.train_step_loss(data.x, data.y, torch.from_numpy(node), torch.from_numpy(src),
+                                           torch.from_numpy(dst), B, leaf)
+        loss.backward()
+        losses.append(float(loss.detach()))
+        for p, lf, st in zip(params, leaf, state):
+            for k in p:
+                p[k], m, v = sage_ref.adam_ref(p[k], lf[k].grad, st[k][0], st[k][1], step, lr)
+                st[k] = (m, v)
+    return losses, params
+
+
+def _oracle_accuracy(data, params, seeds, fanout, rng_seed, counter0, B):
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), data.num_nodes)
+    hit = 0
+    for b in range(0, len(seeds), B):
+        chunk = seeds[b:b + B]
+        node, src, dst, _, _, _ = sampler.neighbor_sample(c0, r0, chunk.numpy(), fanout, rng_seed, counter0 + b // B)
+        out = sage_ref.graphsage_forward(data.x[node], torch.from_numpy(np.stack([src, dst])), params)
+        hit += int((out[:len(chunk)].argmax(-1) == data.y[chunk]).sum())
+    return hit / len(seeds)
+
+
+def test_engine_loss_curve_and_f1_match_oracle(dev):
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    ds = _dataset()
+    data = ds[0]
+    B, fan, lr = 64, [6, 4], 1e-2
+    layers = make_layers([24, 16, 5], "mean", 5)
+    model = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
+    load_layers(model, layers)
+    graph = device_graph(data)
+    engine = SageTrainEngine(model, NeighborSampler(data, fan, seed=13), graph.features(data),
+                             graph.labels(data), B, lr=lr)
+    train = data.train_mask.nonzero().view(-1)
+    steps = 20
+    batches = [train[(s % 10) * B:(s % 10 + 1) * B] for s in range(steps)]
+    counters = list(range(100, 100 + steps))
+    want, params = _oracle_train(data, layers, batches, fan, 13, counters, lr, B)
+    got = [float(engine.step(b.to(dev), counter=c)) for b, c in zip(batches, counters)]
+    # loss curve within 1e-4 relative for 20 steps
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    assert want[-1] < want[0]
+    # evaluation: same sampled neighbourhoods, same weights to 1e-4 => same predictions up to ties
+    test_ids = data.test_mask.nonzero().view(-1)
+    correct, count = engine.evaluate(test_ids.to(dev), counter0=7000)
+    acc = int(correct) / int(count)
+    acc_ref = _oracle_accuracy(data, params, test_ids, fan, 13, 7000, B)
+    assert int(count) == 400
+    assert abs(acc - acc_ref) <= 0.005, (acc, acc_ref)      # within 0.5 pt micro-F1
+    assert acc > 0.5
+
+
+def test_train_epoch_matches_step_loop(dev):
+    from graphsage_amd.dist import batch_counter
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = _dataset()[0]
+    B, fan = 64, [5, 3]
+    torch.manual_seed(0)
+    model_a = GraphSAGE(24, 16, "sum", 2, 5).to(dev)
+    model_b = copy.deepcopy(model_a)
+    graph = device_graph(data)
+    mk = lambda m: SageTrainEngine(m, NeighborSampler(data, fan, seed=2), graph.features(data),
+                                   graph.labels(data), B, lr=1e-2)
+    ea, eb = mk(model_a), mk(model_b)
+    seeds = data.train_mask.nonzero().view(-1).to(dev)[:5 * B + 17]      # tail of 17 is dropped
+    mean_loss = ea.train_epoch(seeds, epoch=3)
+    losses = [eb.step(seeds[b * B:(b + 1) * B], counter=batch_counter(3, 5, b, 0, 1)).clone() for b in range(5)]
+    torch.testing.assert_close(mean_loss, torch.stack(losses).mean(0), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ea.flat, eb.flat, rtol=1e-4, atol=1e-6)
+    assert int(ea.step_dev) == 5
+
+
+@pytest.mark.parametrize("supervised_only", [True, False])
+def test_supervised_trainer_runs_and_learns(dev, supervised_only):
+    from graphsage_amd import settings
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    from graphsage_amd.trainers import SupervisedGraphSageTrainerForNodeLevelTask, dataloader_kwargs
+    ds = _dataset(noise=1.0)
+    data = ds[0]
+    torch.manual_seed(0)
+    model = GraphSAGE(ds.num_features, 32, "mean", 2, ds.num_classes).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    old = dict(dataloader_kwargs)
+    dataloader_kwargs['batch_size'] = 128
+    try:
+        tr = SupervisedGraphSageTrainerForNodeLevelTask(
+            data, UniformLoader, loss_fn=F.cross_entropy, model=model, optimizer=opt, num_epochs=3, device=dev,
+            k1=6, k2=4, dataset_name='planted', supervised_only=supervised_only)
+    finally:
+        dataloader_kwargs.update(old)
+    assert (tr.engine is not None) == supervised_only
+    best = tr.run(verbose=False)
+    assert set(best) >= {'loss', 'val_acc', 'val_f1', 'test_acc', 'test_f1', 'train_time', 'test_time'}
+    assert best['val_f1'] == best['val_acc'] and best['test_f1'] > 0.6
+    assert tr.results[-1]['loss'] < tr.results[0]['loss']
+    assert len(tr.results) == 3
+
+
+def test_unsupervised_trainer_runs(dev):
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    from graphsage_amd.trainers import UnsupervisedGraphSageTrainerForNodeLevelTask, dataloader_kwargs
+    ds = _dataset(noise=1.0)
+    data = ds[0]
+    torch.manual_seed(0)
+    model = GraphSAGE(ds.num_features, 32, "mean", 2).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    old = dict(dataloader_kwargs)
+    dataloader_kwargs['batch_size'] = 128
+    try:
+        tr = UnsupervisedGraphSageTrainerForNodeLevelTask(data, UniformLoader, model=model, optimizer=opt,
+                                                          num_epochs=2, device=dev, k1=6, k2=4)
+    finally:
+        dataloader_kwargs.update(old)
+    best = tr.run(verbose=False)
+    assert best['test_f1'] > 0.5 and best['loss'] > 0
+    assert tr.results[-1]['loss'] < tr.results[0]['loss'] + 0.1
+
+
+@pytest.mark.parametrize("aggregator", ["mean", "max_pool"])
+def test_fig2a_harness(dev, aggregator):
+    from graphsage_amd.experiments import fig2a
+    ds = _dataset(noise=1.0)
+    out = fig2a.get(aggregator, dataset=ds, num_epochs=2, batch_size=128, k1=6, k2=4, verbose=False).run()
+    assert set(out) >= {'test_time', 'train_time'}
+    assert out['engine'] == (aggregator == "mean")
+    assert out['train_time'] > 0 and out['test_time'] > 0 and out['test_acc'] > 0.5
