@@ -52,7 +52,9 @@ class GraphSAGE(torch.nn.Module):
             for i, layer in enumerate(self.layers):
                 x = layer(x, edge_index)
                 if i < len(self.layers) - 1:
-                    x = x.relu_()
+                    # out of place: the normalise Function saved its output for backward (the
+                    # reference's relu_() at models/graphsage.py:48 has the same values)
+                    x = x.relu()
             return x
         L = len(self.layers)
         for i, layer in enumerate(self.layers):

@@ -1,0 +1,69 @@
+"""The committed golden vectors (tests/golden/*.npz, written by tests/golden/make_golden.py) pin the
+CPU oracle: the numpy sampler, the C sampler, to_csc and the torch restatement of the fig2a step
+must keep reproducing them.  Parity with the reference itself stays unpinned."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csc, sage_ref, sampler, sampler_c
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SAMPLER_FILES = sorted(glob.glob(os.path.join(GOLD, "sampler_*.npz")))
+MODEL_FILES = sorted(glob.glob(os.path.join(GOLD, "model_small_*.npz")))
+
+
+def test_golden_files_present():
+    assert len(SAMPLER_FILES) == 3 and len(MODEL_FILES) == 4
+
+
+@pytest.mark.parametrize("path", SAMPLER_FILES, ids=os.path.basename)
+def test_oracle_sampler_reproduces_golden(path):
+    g = np.load(path)
+    n = int(g["num_nodes"])
+    colptr, row, perm = csc.to_csc(g["edge_index"].astype(np.int64), n)
+    assert colptr.tolist() == g["colptr"].tolist()
+    assert row.tolist() == g["row"].tolist() and perm.tolist() == g["perm"].tolist()
+    fan = g["fanout"].tolist()
+    impls = [sampler.neighbor_sample]
+    if sampler_c.available():
+        impls.append(sampler_c.neighbor_sample)
+    for fn in impls:
+        node, src, dst, eid, hop_nodes, hop_edges = fn(colptr, row, g["seeds"], fan, int(g["rng_seed"]),
+                                                       int(g["counter"]))
+        assert node.tolist() == g["node"].tolist()
+        assert src.tolist() == g["src"].tolist() and dst.tolist() == g["dst"].tolist()
+        assert eid.tolist() == g["eid"].tolist()
+        assert list(hop_nodes) == g["hop_nodes"].tolist() and list(hop_edges) == g["hop_edges"].tolist()
+    # structural invariants of the stored vectors themselves (SURVEY §8c sampler KATs)
+    node, src, dst, eid = (g[k].astype(np.int64) for k in ("node", "src", "dst", "eid"))
+    B = len(g["seeds"])
+    assert node[:B].tolist() == g["seeds"].tolist()
+    assert len(set(node[B:].tolist())) == len(node) - B
+    assert (row[eid] == node[src]).all()
+    owner = np.searchsorted(colptr, eid, side="right") - 1
+    assert (owner == node[dst]).all()
+    assert (np.diff(dst) >= 0).all()                       # grouped by target, frontier order
+
+
+@pytest.mark.parametrize("path", MODEL_FILES, ids=os.path.basename)
+def test_oracle_step_reproduces_golden(path):
+    agg = os.path.basename(path)[len("model_small_"):-len(".npz")]
+    g = np.load(path)
+    s = np.load(os.path.join(GOLD, "sampler_small.npz"))
+    n_layers = len(g["dims"]) - 1
+    layers = []
+    for i in range(n_layers):
+        layers.append({k[len(f"w{i}_"):]: torch.from_numpy(g[k]).clone().requires_grad_(True)
+                       for k in g.files if k.startswith(f"w{i}_")})
+    t = lambda k: torch.from_numpy(s[k].astype(np.int64))
+    loss, y_hat = sage_ref.train_step_loss(torch.from_numpy(g["x"]), torch.from_numpy(g["y"]), t("node"), t("src"),
+                                           t("dst"), len(s["seeds"]), layers, agg)
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-6)
+    np.testing.assert_allclose(y_hat.detach().numpy(), g["y_hat"], rtol=1e-5, atol=1e-6)
+    for i, p in enumerate(layers):
+        for k, v in p.items():
+            np.testing.assert_allclose(v.grad.numpy(), g[f"g{i}_{k}"], rtol=1e-4, atol=1e-7)
