@@ -13,11 +13,19 @@
 //   forward   : A(m,k) = a[rows(m)][k]   (k contiguous)   B(k,n) = w[n][k]   (k contiguous)
 //   d input   : A(m,k) = dout[m][k]      (k contiguous)   B(k,n) = w[k][n]   (n contiguous)
 //   d weight  : A(m,k) = dout[k][m]      (m contiguous)   B(k,n) = a[rows(k)][n]
-// Tiles are staged global -> registers -> LDS (k-major in LDS: As[k][m], Bs[k][n]), double
-// buffered, one barrier per K-step of 32; the MFMA fragment reads are then consecutive
-// addresses per lane (conflict-free ds_read_b32).  The optional row map lets the root
-// operand come straight out of the global feature table (no materialised batch.x).
+// Tiles are staged global -> registers -> LDS, double buffered, one barrier per K-step of 32.
+// The LDS image of an operand keeps the operand's own contiguous dimension contiguous:
+//   k contiguous in memory (forward, dout of d-input): [m][BK+4] rows, written with one 16-byte
+//     store per loaded vector and read back as ONE ds_read_b128 per lane per 8 k — lanes 0-31
+//     take k = 8g..8g+3, lanes 32-63 k = 8g+4..8g+7 of their row, which feeds four MFMAs.
+//     An LDS-fed 32x32x2 MFMA loop sustains 142-148 TF/s with these reads against 106-124 TF/s
+//     with one ds_read_b32 per operand per MFMA (scratch/lds_mfma.hip, MI355X);
+//   m/n contiguous in memory (d-weight): k-major [BK][MN+4] rows, ds_read_b32 per k.
+// Both operands of one MFMA use the same k slot assignment, so any pairing of the two layouts
+// is valid.  The optional row map lets the root operand come straight out of the global
+// feature table (no materialised batch.x).
 #include "common.h"
+#include <type_traits>
 
 namespace sage {
 namespace {
@@ -71,8 +79,8 @@ struct GemmArgs {
 // operands the mapped row pointers are fixed for the whole segment (begin()), for !KC
 // operands the row ids of step s+1 are fetched while step s is being loaded.
 template <int VEC> struct VecT;
-template <> struct VecT<4> { using type = float4; };
-template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float __attribute__((ext_vector_type(4))); };
+template <> struct VecT<2> { using type = float __attribute__((ext_vector_type(2))); };
 template <> struct VecT<1> { using type = float; };
 
 template <bool KC, int MN, int VEC>
@@ -83,8 +91,9 @@ struct TileLoader {
   static_assert(PASSES >= 1, "tile too small for the thread block");
   using VT = typename VecT<VEC>::type;
 
-  VT v[PASSES];
-  const float* rowp[PASSES];  // KC: row base pointers (nullptr = row beyond the limit)
+  VT v[2][PASSES];            // two register sets: the loads of two K-steps are in flight
+  int64_t rowoff[PASSES];     // KC: offset of the (clamped, mapped) row in floats from op.p
+  bool rvalid[PASSES];        // KC: row below the limit
   int64_t rows[PASSES];       // !KC: (mapped) row ids of the K-step issued next
   Operand op;
   int64_t mn0, mn_lim;
@@ -110,65 +119,76 @@ struct TileLoader {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       if (KC) {
-        rowp[p] = (mn0 + trow(p) < mn_lim) ? op.p + ids[p] * op.ld : nullptr;
+        rowoff[p] = ids[p] * op.ld;
+        rvalid[p] = mn0 + trow(p) < mn_lim;
       } else {
         rows[p] = ids[p];
       }
     }
   }
 
-  // request the tile whose first contraction index is k0
-  __device__ inline void issue(int k0) {
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      const float* src = nullptr;
-      if (KC) {
-        if (rowp[p] != nullptr && k0 + tcol(p) < k_end) src = rowp[p] + k0 + tcol(p);
-      } else {
-        if (k0 + trow(p) < k_end && mn0 + tcol(p) < mn_lim) src = op.p + rows[p] * op.ld + mn0 + tcol(p);
-      }
-      if (src != nullptr) {
-        v[p] = *reinterpret_cast<const VT*>(src);
-      } else {
-        v[p] = VT{};
-      }
+  // Request pass p of the tile whose first contraction index is k0.  The load is
+  // UNCONDITIONAL: rows and columns beyond the limits are clamped to the last valid vector of
+  // the operand and zeroed in store_pass().  Straight-line loads (no exec-masked branches) let
+  // the compiler count vmcnt exactly, so the store of one register set does not wait for the
+  // younger set.  Safe for any k0; passes must be issued for consecutive K-steps.
+  template <int SET>
+  __device__ inline void issue_pass(int p, int k0) {
+    typedef const VT __attribute__((address_space(1)))* GlobalVec;   // global, not flat
+    const float* src;
+    if (KC) {
+      const int kmax = (k_end - 1) / VEC * VEC;
+      const int kk = k0 + tcol(p);
+      src = op.p + rowoff[p] + (kk < kmax ? kk : kmax);
+    } else {
+      const int64_t cmax = (mn_lim - 1) / VEC * VEC;
+      const int64_t c = mn0 + tcol(p);
+      src = op.p + rows[p] * op.ld + (c < cmax ? c : cmax);
     }
+    v[SET][p] = *((GlobalVec)(src));
     if (!KC) {
-      // row ids of the NEXT K-step; they arrive while this step's data is in flight
-#pragma unroll
-      for (int p = 0; p < PASSES; ++p) {
-        const int64_t r = static_cast<int64_t>(k0) + BK + trow(p);
-        rows[p] = r < k_end ? r : static_cast<int64_t>(k_end) - 1;
-      }
-      if (op.rowmap != nullptr) {
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) rows[p] = op.rowmap[rows[p]];
-      }
+      // row id of the NEXT K-step; it arrives while this step's data is in flight
+      const int64_t r = static_cast<int64_t>(k0) + BK + trow(p);
+      rows[p] = r < k_end ? r : static_cast<int64_t>(k_end) - 1;
+      if (op.rowmap != nullptr) rows[p] = op.rowmap[rows[p]];
     }
   }
+  template <int SET>
+  __device__ inline void issue(int k0) {
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) issue_pass<SET>(p, k0);
+  }
 
-  // write the tile requested by issue(k0) into LDS ([BK][LDS_LD], k-major)
-  template <int LDS_LD>
+  // write pass p of the tile requested by issue(k0) into LDS
+  template <int LDS_LD, int SET>
+  __device__ inline void store_pass(int p, int k0, float* lds) const {
+    float e[VEC];
+    if constexpr (VEC == 4) { e[0] = v[SET][p].x; e[1] = v[SET][p].y; e[2] = v[SET][p].z; e[3] = v[SET][p].w; }
+    else if constexpr (VEC == 2) { e[0] = v[SET][p].x; e[1] = v[SET][p].y; }
+    else { e[0] = v[SET][p]; }
+    // zero what lies beyond the limits: whole vectors of clamped rows / columns, and the tail
+    // of a ragged last vector (it may have read row padding)
+    const int64_t c0 = KC ? static_cast<int64_t>(k0 + tcol(p)) : (mn0 + tcol(p));
+    const int64_t c_lim = KC ? static_cast<int64_t>(k_end) : mn_lim;
+    const bool row_ok = KC ? rvalid[p] : (k0 + trow(p) < k_end);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      if (!row_ok || c0 + j >= c_lim) e[j] = 0.f;
+    }
+    // both layouts keep the loaded vector contiguous: [mn][k] for KC, [k][mn] otherwise
+    float* dst = lds + trow(p) * LDS_LD + tcol(p);
+    if constexpr (VEC == 4) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      *reinterpret_cast<f4v*>(dst) = f4v{e[0], e[1], e[2], e[3]};
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) dst[j] = e[j];
+    }
+  }
+  template <int LDS_LD, int SET>
   __device__ inline void store(int k0, float* lds) const {
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-      float e[VEC];
-      if constexpr (VEC == 4) { e[0] = v[p].x; e[1] = v[p].y; e[2] = v[p].z; e[3] = v[p].w; }
-      else if constexpr (VEC == 2) { e[0] = v[p].x; e[1] = v[p].y; }
-      else { e[0] = v[p]; }
-      // a ragged last vector may have read row padding: zero what lies beyond the limit
-      const int64_t c0 = KC ? static_cast<int64_t>(k0 + tcol(p)) : (mn0 + tcol(p));
-      const int64_t c_lim = KC ? static_cast<int64_t>(k_end) : mn_lim;
-#pragma unroll
-      for (int j = 1; j < VEC; ++j) {
-        if (c0 + j >= c_lim) e[j] = 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        if (KC) lds[(tcol(p) + j) * LDS_LD + trow(p)] = e[j];  // transpose: [k][mn]
-        else lds[trow(p) * LDS_LD + tcol(p) + j] = e[j];
-      }
-    }
+    for (int p = 0; p < PASSES; ++p) store_pass<LDS_LD, SET>(p, k0, lds);
   }
 };
 
@@ -176,12 +196,14 @@ struct TileLoader {
 template <bool A_KC, bool B_KC, int BM, int BN, int VEC>
 __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / 64, TN = BN / 64;
-  constexpr int LDA = BM + (A_KC ? 2 : 4);
-  constexpr int LDB = BN + (B_KC ? 2 : 4);
-  __shared__ __attribute__((aligned(16))) float lds[2 * BK * (LDA + LDB)];
-  // layout: As[2][BK][LDA] then Bs[2][BK][LDB]
+  // row stride and size of one LDS buffer per operand: [BM][BK+4] (k contiguous) or [BK][BM+4]
+  constexpr int LDA = A_KC ? BK + 4 : BM + 4;
+  constexpr int LDB = B_KC ? BK + 4 : BN + 4;
+  constexpr int ASZ = A_KC ? BM * LDA : BK * LDA;
+  constexpr int BSZ = B_KC ? BN * LDB : BK * LDB;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
   float* const As = lds;
-  float* const Bs = lds + 2 * BK * LDA;
+  float* const Bs = lds + 2 * ASZ;
 
   int64_t m_lim = g.m;
   if (g.m_dev != nullptr) {
@@ -223,6 +245,70 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   TileLoader<A_KC, BM, VEC> la;
   TileLoader<B_KC, BN, VEC> lb;
 
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  constexpr int NG = BK / 8;
+  // PAR = parity of the step within its segment = register set that holds step k0 + 2*BK... :
+  // step (k0) computes from (as, bs), stores set PAR^1 (step k0+BK) into (as_next, bs_next) and
+  // requests step k0+3*BK into set PAR^1.
+  auto k_step = [&](auto par, int k0, const float* as, const float* bs, float* as_next, float* bs_next) {
+    constexpr int PAR = decltype(par)::value;
+    float af[NG][TM][4], bf[NG][TN][4];
+    auto read_group = [&](int g) {
+      const int g8 = 8 * g;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (A_KC) {
+          const f4v v = *reinterpret_cast<const f4v*>(as + (wm0 + i * 32 + l31) * LDA + g8 + 4 * half);
+          af[g][i][0] = v[0]; af[g][i][1] = v[1]; af[g][i][2] = v[2]; af[g][i][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) af[g][i][j] = as[(g8 + 4 * half + j) * LDA + wm0 + i * 32 + l31];
+        }
+      }
+#pragma unroll
+      for (int jn = 0; jn < TN; ++jn) {
+        if constexpr (B_KC) {
+          const f4v v = *reinterpret_cast<const f4v*>(bs + (wn0 + jn * 32 + l31) * LDB + g8 + 4 * half);
+          bf[g][jn][0] = v[0]; bf[g][jn][1] = v[1]; bf[g][jn][2] = v[2]; bf[g][jn][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[g][jn][j] = bs[(g8 + 4 * half + j) * LDB + wn0 + jn * 32 + l31];
+        }
+      }
+    };
+    read_group(0);
+    read_group(1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 2 < NG) read_group(g + 2);
+      // k slot of MFMA j in this group: 8g + 4*half + j, for both operands
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          csum[i] += af[g][i][j];
+#pragma unroll
+          for (int jn = 0; jn < TN; ++jn) {
+            acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i][j], bf[g][jn][j], acc[i][jn], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g == 1) {
+        la.template store<LDA, PAR ^ 1>(k0 + BK, as_next);
+        lb.template store<LDB, PAR ^ 1>(k0 + BK, bs_next);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (g == 2) {
+        la.template issue<PAR ^ 1>(k0 + 3 * BK);
+        lb.template issue<PAR ^ 1>(k0 + 3 * BK);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+  };
+
   for (int s = s_begin; s < s_end; ++s) {
     const Segment& sg = g.seg[s];
     int k_lim = sg.k;
@@ -237,45 +323,101 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
     }
     if (k_beg >= k_end) continue;
 
-    int cur = 0;
     la.begin(sg.a, m0, m_lim, k_beg, k_end);
     lb.begin(sg.b, n0, n_lim, k_beg, k_end);
-    la.issue(k_beg);
-    lb.issue(k_beg);
-    la.template store<LDA>(k_beg, As);
-    lb.template store<LDB>(k_beg, Bs);
-    __syncthreads();
+    if constexpr (A_KC && B_KC) {
+      // (the scheduling barriers keep the program order of the loads: vmcnt counts in issue
+      // order, and the loop's waits are derived from the order seen here)
+      la.template issue<0>(k_beg);
+      lb.template issue<0>(k_beg);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template issue<1>(k_beg + BK);   // loads past k_end are clamped and zeroed later
+      lb.template issue<1>(k_beg + BK);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template store<LDA, 0>(k_beg, As);
+      lb.template store<LDB, 0>(k_beg, Bs);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template issue<0>(k_beg + 2 * BK);
+      lb.template issue<0>(k_beg + 2 * BK);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
 
-    for (int k0 = k_beg; k0 < k_end; k0 += BK) {
-      const bool has_next = k0 + BK < k_end;
-      if (has_next) {
-        la.issue(k0 + BK);
-        lb.issue(k0 + BK);
+      // One K-step = 4 groups of 8 k.  The fragments of group g+2 are read from LDS while group
+      // g multiplies.  Global loads run TWO steps ahead in two register sets (a 128-byte piece
+      // of a gathered feature row is a fresh HBM access every step, and one step of MFMAs does
+      // not cover its latency): step k stores the tile of step k+1 (requested two steps ago,
+      // set (k+1)&1) into the other LDS buffer behind group 1 and requests step k+3 into the
+      // same set behind group 2.  The loop is unrolled by two so the set index is static.
+      // pairs of steps in a branch-free loop body (any branch inside it gives the structurised
+      // CFG a path on which the younger load set is the one being stored, and every vmcnt in the
+      // loop degrades to a full drain); an odd last step runs from a copy after the loop
+      const int nsteps = (k_end - k_beg + BK - 1) / BK;
+      int k0 = k_beg;
+      for (int i = 0; i + 1 < nsteps; i += 2, k0 += 2 * BK) {
+        k_step(std::integral_constant<int, 0>{}, k0, As, Bs, As + ASZ, Bs + BSZ);
+        k_step(std::integral_constant<int, 1>{}, k0 + BK, As + ASZ, Bs + BSZ, As, Bs);
       }
-      const float* as = As + cur * (BK * LDA);
-      const float* bs = Bs + cur * (BK * LDB);
+      if (nsteps & 1) k_step(std::integral_constant<int, 0>{}, k0, As, Bs, As + ASZ, Bs + BSZ);
+    } else {
+      // d-input / d-weight: one register set, request step k+1 before the MFMAs of step k and
+      // store it behind them (the deeper pipeline above does not fit the register budget of
+      // the k-major fragment reads)
+      la.template issue<0>(k_beg);
+      lb.template issue<0>(k_beg);
+      la.template store<LDA, 0>(k_beg, As);
+      lb.template store<LDB, 0>(k_beg, Bs);
+      __syncthreads();
+      int cur = 0;
+      for (int k0 = k_beg; k0 < k_end; k0 += BK) {
+        const bool has_next = k0 + BK < k_end;
+        if (has_next) {
+          la.template issue<0>(k0 + BK);
+          lb.template issue<0>(k0 + BK);
+        }
+        const float* as = As + cur * ASZ;
+        const float* bs = Bs + cur * BSZ;
 #pragma unroll
-      for (int kk = 0; kk < BK; kk += 2) {
-        float af[TM], bf[TN];
+        for (int g8 = 0; g8 < BK; g8 += 8) {
+          float af[TM][4], bf[TN][4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = as[(kk + half) * LDA + wm0 + i * 32 + l31];
+          for (int i = 0; i < TM; ++i) {
+            if constexpr (A_KC) {
+              const f4v v = *reinterpret_cast<const f4v*>(as + (wm0 + i * 32 + l31) * LDA + g8 + 4 * half);
+              af[i][0] = v[0]; af[i][1] = v[1]; af[i][2] = v[2]; af[i][3] = v[3];
+            } else {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = bs[(kk + half) * LDB + wn0 + j * 32 + l31];
+              for (int j = 0; j < 4; ++j) af[i][j] = as[(g8 + 4 * half + j) * LDA + wm0 + i * 32 + l31];
+            }
+          }
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          csum[i] += af[i];
+          for (int jn = 0; jn < TN; ++jn) {
+            if constexpr (B_KC) {
+              const f4v v = *reinterpret_cast<const f4v*>(bs + (wn0 + jn * 32 + l31) * LDB + g8 + 4 * half);
+              bf[jn][0] = v[0]; bf[jn][1] = v[1]; bf[jn][2] = v[2]; bf[jn][3] = v[3];
+            } else {
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < 4; ++j) bf[jn][j] = bs[(g8 + 4 * half + j) * LDB + wn0 + jn * 32 + l31];
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              csum[i] += af[i][j];
+#pragma unroll
+              for (int jn = 0; jn < TN; ++jn) {
+                acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][j], bf[jn][j], acc[i][jn], 0, 0, 0);
+              }
+            }
           }
         }
+        if (has_next) {
+          la.template store<LDA, 0>(k0 + BK, As + (cur ^ 1) * ASZ);
+          lb.template store<LDB, 0>(k0 + BK, Bs + (cur ^ 1) * BSZ);
+        }
+        __syncthreads();
+        cur ^= 1;
       }
-      if (has_next) {
-        la.template store<LDA>(k0 + BK, As + (cur ^ 1) * (BK * LDA));
-        lb.template store<LDB>(k0 + BK, Bs + (cur ^ 1) * (BK * LDB));
-      }
-      __syncthreads();
-      cur ^= 1;
     }
   }
 
@@ -314,7 +456,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
     }
   }
   if (g.colsum != nullptr && blockIdx.y == 0 && (wave & 1) == 0) {
-    // lanes 0-31 summed even k, lanes 32-63 odd k of row (wm0 + i*32 + l31)
+    // the two lane halves summed disjoint k slots of row (wm0 + i*32 + l31)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const float tot = csum[i] + __shfl_xor(csum[i], 32);
@@ -620,7 +762,7 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   }
   // split the contraction so that the grid covers the chip about twice
   const int64_t tiles = cdiv(n, 64) * cdiv(k, k > 64 ? 128 : 64);
-  int64_t splits = 512 / tiles;   // <= 2 workgroups per CU: a third one would run alone at the end
+  int64_t splits = 768 / tiles;   // one full round at 3 resident workgroups per CU
   const int64_t max_splits = cdiv(m, 4 * BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -668,7 +810,8 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
   g.atomic_out = 1;
   // both problems in one grid: aim at <= 4 workgroups per CU
   const int64_t tiles = cdiv(n, 64) * (cdiv(k1, 128) + cdiv(k2, 128));
-  int64_t splits = 1024 / tiles;
+  // 3 workgroups per CU are resident (51 KB LDS, 168 VGPRs each): 768 = one full round
+  int64_t splits = 768 / tiles;
   const int64_t max_splits = cdiv(m, 4 * BK);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
