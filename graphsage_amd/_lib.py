@@ -59,13 +59,68 @@ SIGNATURES = {
 }
 
 _lib = None
+_tape = None      # list being recorded (see recording()), else None
+
+
+class _Recorder:
+    """Stands in for the CDLL while a tape is recorded: every entry point is called as usual
+    and (function, arguments) is appended to the tape."""
+
+    def __init__(self, lib):
+        self._lib = lib
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+
+        def call(*args):
+            _tape.append((fn, args, name))
+            return fn(*args)
+        return call
+
+
+class recording:
+    """Context manager: record the C-ABI calls made inside it.
+
+    A static-shape caller (graphsage_amd/engine.py) issues the same calls with the same pointers
+    every step; replaying the tape skips the per-call tensor validation and marshalling of
+    graphsage_amd/ops.py — the host-side counterpart of a HIP graph, without the graph's
+    per-node launch cost.  The arguments captured include the stream handle: a tape belongs to
+    the stream it was recorded on.  `tape_py(fn)` adds a plain Python callable (a torch op that
+    sits between two library calls) at the current position."""
+
+    def __enter__(self):
+        global _tape
+        if _tape is not None:
+            raise RuntimeError("nested recording")
+        load()
+        _tape = []
+        return _tape
+
+    def __exit__(self, *exc):
+        global _tape
+        _tape = None
+        return False
+
+
+def tape_py(fn):
+    """Run fn() now and, while recording, remember it for replay."""
+    if _tape is not None:
+        _tape.append((fn, (), None))
+    fn()
+
+
+def replay(tape):
+    for fn, args, name in tape:
+        rc = fn(*args)
+        if name is not None and rc != 0:
+            check(rc, name)
 
 
 def load():
     """Load libsage_hip.so once; raise RuntimeError if it is not built."""
     global _lib
     if _lib is not None:
-        return _lib
+        return _Recorder(_lib) if _tape is not None else _lib
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `make -C graphsage_amd/csrc` "
@@ -76,7 +131,7 @@ def load():
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
-    return lib
+    return _Recorder(_lib) if _tape is not None else _lib
 
 
 def last_error():

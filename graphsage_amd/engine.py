@@ -16,7 +16,7 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
 """
 import torch
 
-from . import ops
+from . import _lib, ops
 from .dist import all_reduce_flat
 
 _REDUCE = {'mean': 'mean', 'sum': 'sum'}
@@ -148,6 +148,7 @@ class SageTrainEngine:
         self.state_sum = torch.zeros(ops.STATE_WORDS, dtype=torch.int64, device=dev)
         self.counter = 0
         self.graphs = None
+        self._tapes = {}        # recorded C-ABI call sequences, keyed by (what, slot, ..., stream)
         # pipelining state
         self.side = torch.cuda.Stream(device=dev)
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]      # slot sampled
@@ -161,32 +162,81 @@ class SageTrainEngine:
         return self.bufs[self.last_slot] if hasattr(self, 'last_slot') else self.bufs[0]
 
     # ------------------------------------------------------------------ pieces
-    def sample(self, seeds, counter, slot=0, ctrl=None):
-        """Enqueue the sampler for the batch `seeds[offset : offset+B]` (offset from ctrl or 0)."""
-        if ctrl is None:
-            self._stamp += 1
-            stamp = self._stamp
+    def sample(self, seeds, counter, slot=0, ctrl=None, stream=None):
+        """Enqueue the sampler for the batch `seeds[offset : offset+B]` (offset from ctrl or 0)
+        on `stream` (a torch stream; default: the current one)."""
+        if ctrl is not None:       # graph capture: the device control block carries the running stamp
+            ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed, counter,
+                              self.table, 1, self.bufs[slot], ctrl=ctrl, num_seeds=self.B)
+            return
+        self._stamp += 1
+        handle = (stream or torch.cuda.current_stream()).cuda_stream
+        key = ('sample', slot, handle)
+        entry = self._tapes.get(key)
+        if entry is None:
+            # first call on this (slot, stream): through the validating wrapper, recorded
+            if stream is not None and stream != torch.cuda.current_stream():
+                with torch.cuda.stream(stream), _lib.recording() as tape:
+                    ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed,
+                                      counter, self.table, self._stamp, self.bufs[slot], num_seeds=self.B)
+            else:
+                with _lib.recording() as tape:
+                    ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed,
+                                      counter, self.table, self._stamp, self.bufs[slot], num_seeds=self.B)
+            fn, args, name = tape[0]
+            self._tapes[key] = (fn, list(args), name)
+            return
+        # later calls: same pointers except the seeds, the Philox counter and the stamp
+        if not (seeds.is_cuda and seeds.dtype == torch.int64 and seeds.dim() == 1 and seeds.is_contiguous()
+                and seeds.numel() >= self.B):
+            raise RuntimeError("sample: seeds must be a contiguous CUDA int64 vector of at least B elements")
+        fn, args, name = entry
+        args[3] = seeds.data_ptr()
+        args[8] = int(counter) & 0xFFFFFFFFFFFFFFFF
+        args[10] = self._stamp
+        _lib.check(fn(*args), name)
+
+    def _taped(self, what, slot, fn):
+        """Run fn() through the validating wrappers once per (what, slot, stream) and replay the
+        recorded C-ABI calls afterwards: every pointer the engine passes is static."""
+        key = (what, slot, torch.cuda.current_stream().cuda_stream)
+        tape = self._tapes.get(key)
+        if tape is None:
+            with _lib.recording() as tape:
+                fn()
+            self._tapes[key] = tape
         else:
-            stamp = 1          # the device control block carries the running stamp
-        ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed, counter,
-                          self.table, stamp, self.bufs[slot], ctrl=ctrl, num_seeds=self.B)
+            _lib.replay(tape)
 
     def gather_layer0(self, slot=0):
+        self._taped('gather0', slot, lambda: self._gather_layer0(slot))
+
+    def _gather_layer0(self, slot):
         a, buf = self.act[0], self.bufs[slot]
         ops.gather_reduce_fwd(self.features, buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
                               node_map=buf.node, num_targets_dev=self.n_dev[slot][a['hop']],
                               out=self.agg0[slot], want_argmax=False)
 
     def forward_backward(self, slot=0, skip_gather0=False):
-        self.forward(slot, skip_gather0)
-        self.backward(slot)
+        self.last_slot = slot
+
+        def both():
+            self._forward(slot, skip_gather0)
+            self._backward(slot)
+        self._taped('fb%d' % skip_gather0, slot, both)
 
     def forward(self, slot=0, skip_gather0=False):
         """Layers + normalised logits + per-row cross entropy (and dz of the last layer, which
         the fused kernel produces in the same pass)."""
-        L, buf = self.L, self.bufs[slot]
         self.last_slot = slot
-        self.state_sum.add_(buf.state)
+        self._taped('f%d' % skip_gather0, slot, lambda: self._forward(slot, skip_gather0))
+
+    def backward(self, slot=0):
+        self._taped('b', slot, lambda: self._backward(slot))
+
+    def _forward(self, slot, skip_gather0):
+        L, buf = self.L, self.bufs[slot]
+        _lib.tape_py(lambda: self.state_sum.add_(buf.state))
         x, node_map = self.features, buf.node
         lib = ops
         for i, layer in enumerate(self.model.layers):
@@ -195,7 +245,7 @@ class SageTrainEngine:
             agg = self.agg0[slot] if i == 0 else a['agg']
             if i == 0:
                 if not skip_gather0:
-                    self.gather_layer0(slot)
+                    self._gather_layer0(slot)
             else:
                 lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
                                       num_targets_dev=t_dev, out=agg, want_argmax=False)
@@ -209,10 +259,10 @@ class SageTrainEngine:
         lib.logits_xent_fused(last['z'], self.labels, buf.node, self.B, last['y'], last['inv'], last['dz'],
                               self.row_loss, self.loss)
 
-    def backward(self, slot=0):
+    def _backward(self, slot):
         L, buf = self.L, self.bufs[slot]
         lib = ops
-        self.grad.zero_()
+        _lib.tape_py(self.grad.zero_)
         # (the upper layers' weight gradients are leaves of the dependency chain, but forking
         # them onto another stream costs more in cross-queue waits than the ~20 us it hides:
         # measured 0.41 -> 0.45 ms/step on MI355X / ROCm 7.2, so everything stays on one stream)
@@ -227,7 +277,7 @@ class SageTrainEngine:
                                 x_in, self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
             if i > 0:
                 prev = self.act[i - 1]
-                prev['dh'].zero_()
+                _lib.tape_py(prev['dh'].zero_)
                 lib.linear_dinput(a['dz'], layer.lin_r.weight, m=t_cap, m_dev=t_dev, out=prev['dh'])
                 lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
@@ -238,6 +288,9 @@ class SageTrainEngine:
             all_reduce_flat(self.grad, self.pg)
 
     def optimizer_step(self):
+        self._taped('adam', 0, self._optimizer_step)
+
+    def _optimizer_step(self):
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
                       grad_scale=1.0 / self.world_size)
@@ -264,16 +317,16 @@ class SageTrainEngine:
         (and, with overlap_gather, run that batch's layer-0 gather there too)."""
         slot = self.use if not self.primed else 1 - self.use
         main = torch.cuda.current_stream()
-        with torch.cuda.stream(self.side):
-            self.side.wait_stream(main) if not self.primed else self.side.wait_event(self.consumed[slot])
-            self.sample(seeds, counter, slot=slot)
-            if self.overlap_gather:
+        self.side.wait_stream(main) if not self.primed else self.side.wait_event(self.consumed[slot])
+        self.sample(seeds, counter, slot=slot, stream=self.side)
+        if self.overlap_gather:
+            with torch.cuda.stream(self.side):
                 if before_gather is not None:
                     before_gather()
                 self.gather_layer0(slot)
                 if after_gather is not None:
                     after_gather()
-            self.ready[slot].record(self.side)
+        self.ready[slot].record(self.side)
         seeds.record_stream(self.side)
         self.primed = True
 
