@@ -26,6 +26,7 @@ SIGNATURES = {
                                         c_uint64, c_uint64, _P, c_uint32, _P, c_int64, c_int64,
                                         _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sage_ctrl_advance": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P]),
+    "sage_state_accumulate": (c_int, [_P, _P, _P]),
     "sage_random_neighbor": (c_int, [_P, _P, _P, c_int64, c_uint64, c_uint64, _P, _P]),
     "sage_gather_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, c_int64, _P]),
     "sage_gather_reduce_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int,
@@ -49,13 +50,13 @@ SIGNATURES = {
     "sage_l2norm_relu_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int, _P, c_int64, _P, c_int64,
                                      _P, _P]),
     "sage_l2norm_relu_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int64, _P, c_int,
-                                     _P, c_int64, _P]),
+                                     _P, c_int64, c_int, _P]),
     "sage_softmax_xent": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, c_int64,
                                   _P]),
     "sage_logits_xent_fused": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P,
-                                       _P, c_int64, _P, _P, _P]),
+                                       _P, c_int64, _P, _P, c_int, _P]),
     "sage_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
-                               c_float, c_float, _P, _P]),
+                               c_float, c_float, _P, _P, c_int, _P]),
 }
 
 _lib = None

@@ -12,4 +12,4 @@ void set_error(const char* fmt, ...) {
 }  // namespace sage
 
 extern "C" const char* sage_last_error(void) { return sage::g_err; }
-extern "C" int sage_abi_version(void) { return 1; }
+extern "C" int sage_abi_version(void) { return 2; }

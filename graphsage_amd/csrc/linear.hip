@@ -656,6 +656,8 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
                "sage_linear_concat_fwd: NULL pointer argument");
   SAGE_REQUIRE(!(epilogue & SAGE_EPI_BIAS) || bias != nullptr, SAGE_EINVAL,
                "sage_linear_concat_fwd: SAGE_EPI_BIAS without bias");
+  SAGE_REQUIRE(!(epilogue & SAGE_EPI_ACCUM) || epilogue == SAGE_EPI_ACCUM, SAGE_EINVAL,
+               "sage_linear_concat_fwd: SAGE_EPI_ACCUM excludes bias / relu");
   GemmArgs g = {};
   g.seg[0].a = {a1, ld_a1, rows1, op_vec(a1, ld_a1, k1)};
   g.seg[0].b = {w1, ld_w1, nullptr, op_vec(w1, ld_w1, k1)};
@@ -679,16 +681,18 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
   // sums are combined with fp32 atomics into a zeroed output.
   const int64_t tiles = cdiv(m, 64) * cdiv(n, n > 64 ? 128 : 64);
   const int kmax = k1 > k2 ? k1 : k2;
-  if (epilogue == SAGE_EPI_NONE && tiles <= 32 && kmax >= 4 * BK) {
+  const bool accum = (epilogue & SAGE_EPI_ACCUM) != 0;
+  if ((epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && tiles <= 32 && kmax >= 4 * BK) {
     int splits = kmax / (2 * BK);
     if (splits > 8) splits = 8;
     g.k_chunk = static_cast<int>(cdiv(cdiv(kmax, splits), BK) * BK);
     splits = static_cast<int>(cdiv(kmax, g.k_chunk));
     g.atomic_out = 1;
-    zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
+    if (!accum) zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
     SAGE_CHECK_LAUNCH("zero_rows_kernel");
     return launch_gemm<true, true>(g, splits, stream, "gemm_kernel(fwd, split-K)");
   }
+  if (accum) g.atomic_out = 1;   // out += product
   return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");
 }
 

@@ -53,16 +53,16 @@ l2norm_relu_fwd_kernel(const float* __restrict__ z, int64_t ld_z, int64_t m,
 }
 
 __global__ void __launch_bounds__(kBlock)
-l2norm_relu_bwd_kernel(const float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ y,
+l2norm_relu_bwd_kernel(float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ y,
                        int64_t ld_y, const float* __restrict__ inv_norm, int relu_mask, int64_t m,
                        const int64_t* __restrict__ m_dev, int n, float* __restrict__ dz,
-                       int64_t ld_dz) {
+                       int64_t ld_dz, int clear_dh) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t rows = dev_count(m_dev, m);
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
   if (r >= rows) return;
   const float* yr = y + r * ld_y;
-  const float* gr = dh + r * ld_dh;
+  float* gr = dh + r * ld_dh;
   const float inv = inv_norm[r];
   const bool clamped = inv >= 1.f / kNormEps;  // ||z|| <= eps: the clamp's gradient is zero
   float dot = 0.f;
@@ -78,6 +78,8 @@ l2norm_relu_bwd_kernel(const float* __restrict__ dh, int64_t ld_dh, const float*
     float g = gr[f];
     if (relu_mask && !(yv > 0.f)) g = 0.f;
     dz[r * ld_dz + f] = (g - yv * dot) * inv;
+    // consume-and-clear: the next step's scatter-add starts from zeros without a fill kernel
+    if (clear_dh) gr[f] = 0.f;
   }
 }
 
@@ -161,16 +163,16 @@ softmax_xent_kernel(const float* __restrict__ logits, int64_t ld_logits,
 // row-local, so one wave per row replaces l2norm_fwd + softmax_xent + l2norm_bwd (and the
 // single-workgroup loss kernel's serial walk over the rows).
 __global__ void __launch_bounds__(kBlock)
-logits_xent_fused_kernel(const float* __restrict__ z, int64_t ld_z,
+logits_xent_fused_kernel(float* __restrict__ z, int64_t ld_z,
                          const int64_t* __restrict__ labels, const int64_t* __restrict__ label_rows,
                          int64_t m, int n, float grad_scale, float* __restrict__ y, int64_t ld_y,
                          float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
-                         float* __restrict__ row_loss) {
+                         float* __restrict__ row_loss, int clear_z) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
   if (r >= m) return;
   const int64_t lab = labels[label_rows != nullptr ? label_rows[r] : r];
-  const float* zr = z + r * ld_z;
+  float* zr = z + r * ld_z;
   float ss = 0.f;
   for (int f = lane; f < n; f += kWave) {
     const float v = zr[f];
@@ -211,6 +213,7 @@ logits_xent_fused_kernel(const float* __restrict__ z, int64_t ld_z,
     g *= scale;
     if (y != nullptr) y[r * ld_y + f] = yv;
     dz[r * ld_dz + f] = (g - yv * dot) * inv;
+    if (clear_z) zr[f] = 0.f;   // the producer accumulates split-K partial sums into zeros
   }
 }
 
@@ -229,14 +232,19 @@ mean_reduce_kernel(const float* __restrict__ v, int64_t m, float* __restrict__ o
   if (threadIdx.x == 0) out[0] = partial[0] / static_cast<float>(m);
 }
 
-__global__ void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+__global__ void adam_kernel(float* __restrict__ param, const float* grad,
                             float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                             int64_t numel, float lr, float beta1, float beta2, float eps,
                             float weight_decay, float grad_scale,
-                            const int64_t* __restrict__ step_dev) {
+                            const int64_t* __restrict__ step_in, int64_t* __restrict__ step_out,
+                            int zero_grad) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t step = *step_in;
+  // step_out is a different word than step_in (else it is NULL here and a second kernel
+  // bumps the counter): no thread reads what this one writes
+  if (i == 0 && step_out != nullptr) *step_out = step + 1;
   if (i >= numel) return;
-  const float t = static_cast<float>(*step_dev + 1);
+  const float t = static_cast<float>(step + 1);
   const float bc1 = 1.f - powf(beta1, t);
   const float bc2 = 1.f - powf(beta2, t);
   float g = grad[i] * grad_scale;
@@ -248,9 +256,10 @@ __global__ void adam_kernel(float* __restrict__ param, const float* __restrict__
   exp_avg_sq[i] = v1;
   const float denom = sqrtf(v1) / sqrtf(bc2) + eps;
   param[i] = p - (lr / bc1) * (m1 / denom);
+  if (zero_grad) const_cast<float*>(grad)[i] = 0.f;
 }
 
-__global__ void bump_step_kernel(int64_t* step_dev) { *step_dev += 1; }
+__global__ void bump_step2_kernel(const int64_t* step_in, int64_t* step_out) { *step_out = *step_in + 1; }
 
 }  // namespace
 }  // namespace sage
@@ -271,17 +280,17 @@ extern "C" int sage_l2norm_relu_fwd(const float* z, sage_i64 ld_z, sage_i64 m,
   return SAGE_OK;
 }
 
-extern "C" int sage_l2norm_relu_bwd(const float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_y,
+extern "C" int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_y,
                                     const float* inv_norm, int relu_mask, sage_i64 m,
                                     const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
-                                    void* stream_) {
+                                    int clear_dh, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(m >= 0 && n > 0 && ld_dh >= n && ld_y >= n && ld_dz >= n, SAGE_EINVAL,
                "sage_l2norm_relu_bwd: bad shape");
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(dh && y && inv_norm && dz, SAGE_EINVAL, "sage_l2norm_relu_bwd: NULL pointer argument");
   l2norm_relu_bwd_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
-      dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz);
+      dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
   SAGE_CHECK_LAUNCH("l2norm_relu_bwd_kernel");
   return SAGE_OK;
 }
@@ -300,38 +309,41 @@ extern "C" int sage_softmax_xent(const float* logits, sage_i64 ld_logits, const 
   return SAGE_OK;
 }
 
-extern "C" int sage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+extern "C" int sage_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                               sage_i64 numel, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, float grad_scale, sage_i64* step_dev,
-                              void* stream_) {
+                              float weight_decay, float grad_scale, const sage_i64* step_in,
+                              sage_i64* step_out, int zero_grad, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(numel >= 0, SAGE_EINVAL, "sage_adam_step: negative numel");
-  SAGE_REQUIRE(step_dev != nullptr, SAGE_EINVAL, "sage_adam_step: step_dev is NULL");
+  SAGE_REQUIRE(step_in != nullptr && step_out != nullptr, SAGE_EINVAL, "sage_adam_step: step pointer is NULL");
+  const bool in_place = step_in == step_out;
   if (numel > 0) {
     SAGE_REQUIRE(param && grad && exp_avg && exp_avg_sq, SAGE_EINVAL,
                  "sage_adam_step: NULL pointer argument");
     adam_kernel<<<static_cast<unsigned>(cdiv(numel, kBlock)), kBlock, 0, stream>>>(
         param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale,
-        step_dev);
+        step_in, in_place ? nullptr : step_out, zero_grad);
     SAGE_CHECK_LAUNCH("adam_kernel");
   }
-  bump_step_kernel<<<1, 1, 0, stream>>>(step_dev);
-  SAGE_CHECK_LAUNCH("bump_step_kernel");
+  if (in_place || numel == 0) {
+    bump_step2_kernel<<<1, 1, 0, stream>>>(step_in, step_out);
+    SAGE_CHECK_LAUNCH("bump_step_kernel");
+  }
   return SAGE_OK;
 }
 
-extern "C" int sage_logits_xent_fused(const float* z, sage_i64 ld_z, const sage_i64* labels,
+extern "C" int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* labels,
                                       const sage_i64* label_rows, sage_i64 m, int n,
                                       float grad_scale, float* y, sage_i64 ld_y, float* inv_norm,
                                       float* dz, sage_i64 ld_dz, float* row_loss, float* loss,
-                                      void* stream_) {
+                                      int clear_z, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(m > 0 && n > 0 && ld_z >= n && ld_dz >= n && (y == nullptr || ld_y >= n), SAGE_EINVAL,
                "sage_logits_xent_fused: bad shape");
   SAGE_REQUIRE(z && labels && dz && row_loss && loss, SAGE_EINVAL,
                "sage_logits_xent_fused: NULL pointer argument");
   logits_xent_fused_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
-      z, ld_z, labels, label_rows, m, n, grad_scale, y, ld_y, inv_norm, dz, ld_dz, row_loss);
+      z, ld_z, labels, label_rows, m, n, grad_scale, y, ld_y, inv_norm, dz, ld_dz, row_loss, clear_z);
   SAGE_CHECK_LAUNCH("logits_xent_fused_kernel");
   mean_reduce_kernel<<<1, kBlock, 0, stream>>>(row_loss, m, loss);
   SAGE_CHECK_LAUNCH("mean_reduce_kernel");

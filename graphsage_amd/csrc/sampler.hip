@@ -440,6 +440,10 @@ extern "C" int sage_sample_fanout(const sage_i64* colptr, const sage_i64* row, s
 }
 
 namespace {
+__global__ void state_accumulate_kernel(const int64_t* __restrict__ state, int64_t* __restrict__ sum) {
+  sum[threadIdx.x] += state[threadIdx.x];
+}
+
 __global__ void ctrl_advance_kernel(int64_t* ctrl, int64_t d_counter, int64_t d_stamp,
                                     int64_t d_offset, int64_t offset_wrap) {
   ctrl[SAGE_CTRL_COUNTER] += d_counter;
@@ -471,5 +475,12 @@ extern "C" int sage_random_neighbor(const sage_i64* colptr, const sage_i64* row,
       static_cast<uint32_t>(rng_seed >> 32), static_cast<uint32_t>(rng_counter),
       static_cast<uint32_t>(rng_counter >> 32), out);
   SAGE_CHECK_LAUNCH("random_neighbor_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_state_accumulate(const sage_i64* state, sage_i64* sum, void* stream) {
+  SAGE_REQUIRE(state != nullptr && sum != nullptr, SAGE_EINVAL, "sage_state_accumulate: NULL pointer argument");
+  state_accumulate_kernel<<<1, SAGE_STATE_WORDS, 0, static_cast<hipStream_t>(stream)>>>(state, sum);
+  SAGE_CHECK_LAUNCH("state_accumulate_kernel");
   return SAGE_OK;
 }

@@ -74,7 +74,8 @@ class SageTrainEngine:
     """
 
     def __init__(self, model, sampler, features, labels, batch_size, lr=1e-3, betas=(0.9, 0.999),
-                 eps=1e-8, weight_decay=0.0, world_size=1, process_group=None, overlap_gather=False):
+                 eps=1e-8, weight_decay=0.0, world_size=1, process_group=None, overlap_gather=False,
+                 keep_grads=False):
         if model.aggregator not in _REDUCE:
             raise NotImplementedError(f"engine supports {sorted(_REDUCE)}, got {model.aggregator}")
         self.model = model
@@ -114,7 +115,13 @@ class SageTrainEngine:
         self.grad = torch.zeros_like(self.flat)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        # step counter: Adam call k reads word k&1 and writes word (k+1)&1, so the increment
+        # needs no kernel of its own
+        self._steps = torch.zeros(2, dtype=torch.int64, device=dev)
+        self._adam_calls = 0
+        # keep_grads: leave the flat gradient readable after step() (tests); otherwise Adam
+        # clears it for the next step and no fill kernel runs
+        self.keep_grads = bool(keep_grads)
         self.gviews = dict(zip(model.parameters(), views_like(self.grad, self.layout)))
 
         def padded(rows, cols):
@@ -157,6 +164,11 @@ class SageTrainEngine:
         self.primed = False
 
     @property
+    def step_dev(self):
+        """Number of optimizer steps taken (device tensor)."""
+        return self._steps.max()
+
+    @property
     def buf(self):
         """Sample buffers of the batch computed last (slot 0 in the non-pipelined mode)."""
         return self.bufs[self.last_slot] if hasattr(self, 'last_slot') else self.bufs[0]
@@ -168,6 +180,7 @@ class SageTrainEngine:
         if ctrl is not None:       # graph capture: the device control block carries the running stamp
             ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed, counter,
                               self.table, 1, self.bufs[slot], ctrl=ctrl, num_seeds=self.B)
+            ops.state_accumulate(self.bufs[slot].state, self.state_sum)
             return
         self._stamp += 1
         handle = (stream or torch.cuda.current_stream()).cuda_stream
@@ -175,26 +188,29 @@ class SageTrainEngine:
         entry = self._tapes.get(key)
         if entry is None:
             # first call on this (slot, stream): through the validating wrapper, recorded
+            def first():
+                ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed,
+                                  counter, self.table, self._stamp, self.bufs[slot], num_seeds=self.B)
+                ops.state_accumulate(self.bufs[slot].state, self.state_sum)
             if stream is not None and stream != torch.cuda.current_stream():
                 with torch.cuda.stream(stream), _lib.recording() as tape:
-                    ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed,
-                                      counter, self.table, self._stamp, self.bufs[slot], num_seeds=self.B)
+                    first()
             else:
                 with _lib.recording() as tape:
-                    ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed,
-                                      counter, self.table, self._stamp, self.bufs[slot], num_seeds=self.B)
-            fn, args, name = tape[0]
-            self._tapes[key] = (fn, list(args), name)
+                    first()
+            (fn, args, name), acc = tape
+            self._tapes[key] = (fn, list(args), name, acc)
             return
         # later calls: same pointers except the seeds, the Philox counter and the stamp
         if not (seeds.is_cuda and seeds.dtype == torch.int64 and seeds.dim() == 1 and seeds.is_contiguous()
                 and seeds.numel() >= self.B):
             raise RuntimeError("sample: seeds must be a contiguous CUDA int64 vector of at least B elements")
-        fn, args, name = entry
+        fn, args, name, acc = entry
         args[3] = seeds.data_ptr()
         args[8] = int(counter) & 0xFFFFFFFFFFFFFFFF
         args[10] = self._stamp
         _lib.check(fn(*args), name)
+        _lib.check(acc[0](*acc[1]), acc[2])      # state_sum += this batch's sizes, same stream
 
     def _taped(self, what, slot, fn):
         """Run fn() through the validating wrappers once per (what, slot, stream) and replay the
@@ -236,7 +252,6 @@ class SageTrainEngine:
 
     def _forward(self, slot, skip_gather0):
         L, buf = self.L, self.bufs[slot]
-        _lib.tape_py(lambda: self.state_sum.add_(buf.state))
         x, node_map = self.features, buf.node
         lib = ops
         for i, layer in enumerate(self.model.layers):
@@ -249,20 +264,23 @@ class SageTrainEngine:
             else:
                 lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
                                       num_targets_dev=t_dev, out=agg, want_argmax=False)
+            # the logit layer accumulates its split-K partial sums into z, which the fused loss
+            # kernel below hands back zeroed (z starts as zeros): no fill kernel
             lib.linear_concat_fwd(agg, layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
-                                  m_dev=t_dev, rows2=node_map, out=a['z'])
+                                  m_dev=t_dev, rows2=node_map, out=a['z'], accumulate=(i == L - 1))
             if i < L - 1:
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'])
             x, node_map = a.get('h'), None
         # last layer: normalise + cross-entropy on the seed rows + gradient w.r.t. z, one kernel
         last = self.act[-1]
         lib.logits_xent_fused(last['z'], self.labels, buf.node, self.B, last['y'], last['inv'], last['dz'],
-                              self.row_loss, self.loss)
+                              self.row_loss, self.loss, clear_z=True)
 
     def _backward(self, slot):
         L, buf = self.L, self.bufs[slot]
         lib = ops
-        _lib.tape_py(self.grad.zero_)
+        if self.keep_grads:
+            _lib.tape_py(self.grad.zero_)
         # (the upper layers' weight gradients are leaves of the dependency chain, but forking
         # them onto another stream costs more in cross-queue waits than the ~20 us it hides:
         # measured 0.41 -> 0.45 ms/step on MI355X / ROCm 7.2, so everything stays on one stream)
@@ -270,14 +288,14 @@ class SageTrainEngine:
             a, layer = self.act[i], self.model.layers[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
             if i < L - 1:   # g = gradient w.r.t. relu(normalize(z)), left in dh by layer i+1
-                lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'])
+                lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'],
+                                    clear_dh=True)   # dh is zero again for the next step's scatter-add
             x_in = self.features if i == 0 else self.act[i - 1]['h']
             rows = buf.node if i == 0 else None
             lib.linear_dweight2(a['dz'], self.agg0[slot] if i == 0 else a['agg'], self.gviews[layer.lin_l.weight],
                                 x_in, self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
             if i > 0:
                 prev = self.act[i - 1]
-                _lib.tape_py(prev['dh'].zero_)
                 lib.linear_dinput(a['dz'], layer.lin_r.weight, m=t_cap, m_dev=t_dev, out=prev['dh'])
                 lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
@@ -288,12 +306,15 @@ class SageTrainEngine:
             all_reduce_flat(self.grad, self.pg)
 
     def optimizer_step(self):
-        self._taped('adam', 0, self._optimizer_step)
+        par = self._adam_calls & 1
+        self._adam_calls += 1
+        self._taped('adam', par, lambda: self._optimizer_step(par))
 
-    def _optimizer_step(self):
-        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.step_dev, self.lr,
+    def _optimizer_step(self, par):
+        ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._steps[par:par + 1], self.lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                      grad_scale=1.0 / self.world_size)
+                      grad_scale=1.0 / self.world_size, step_out=self._steps[1 - par:2 - par],
+                      zero_grad=not self.keep_grads)
 
     # ------------------------------------------------------------------ one batch at a time
     def step(self, seeds, counter=None):
@@ -427,7 +448,7 @@ class SageTrainEngine:
         cap.wait_stream(torch.cuda.current_stream())
         gs = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
         gc = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
-        ga = torch.cuda.CUDAGraph()
+        ga = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]   # one per step-counter parity
         with torch.cuda.stream(cap):
             for slot in (0, 1):
                 with torch.cuda.graph(gs[slot], stream=cap):
@@ -437,8 +458,12 @@ class SageTrainEngine:
                         self.gather_layer0(slot)
                 with torch.cuda.graph(gc[slot], stream=cap):
                     self.forward_backward(slot=slot, skip_gather0=split_gather or self.overlap_gather)
-            with torch.cuda.graph(ga, stream=cap):
-                self.optimizer_step()
+            # capture executes nothing: the host-side parity must end where it started, and the
+            # first replay must read the word the eager steps wrote last
+            par0 = self._adam_calls & 1
+            for par in (par0, 1 - par0):
+                with torch.cuda.graph(ga[par], stream=cap):
+                    self._optimizer_step(par)
         torch.cuda.current_stream().wait_stream(cap)
         torch.cuda.synchronize()
         self.graphs = (gs, gc, ga)
@@ -480,7 +505,8 @@ class SageTrainEngine:
         gc[p].replay()
         self.last_slot = p
         self.all_reduce()
-        ga.replay()
+        ga[self._adam_calls & 1].replay()
+        self._adam_calls += 1
         self.consumed[p].record(main)
         self.use = 1 - p
         return self.loss

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
-EPI_NONE, EPI_BIAS, EPI_RELU = 0, 1, 2
+EPI_NONE, EPI_BIAS, EPI_RELU, EPI_ACCUM = 0, 1, 2, 4
 
 ST_NODES, ST_EDGES, ST_FRONT_BEGIN, ST_FRONT_END, ST_ERROR = 0, 1, 2, 3, 4
 ST_HOP_NODES, ST_HOP_EDGES, STATE_WORDS = 8, 24, 40
@@ -156,6 +156,14 @@ def sample_fanout(colptr, row, seeds, fanout, rng_seed, rng_counter, table, stam
         _p(buf.seg_ptr, torch.int64, "seg_ptr"), _p(buf.state, torch.int64, "state"),
         c_void_p(buf.ws.data_ptr()), buf.ws_bytes, _stream())
     _lib.check(rc, "sage_sample_fanout")
+
+
+def state_accumulate(state, total):
+    """total += state (both int64[STATE_WORDS] on the device)."""
+    lib = _lib.load()
+    rc = lib.sage_state_accumulate(_vec(state, torch.int64, "state", min_len=STATE_WORDS),
+                                   _vec(total, torch.int64, "total", min_len=STATE_WORDS), _stream())
+    _lib.check(rc, "sage_state_accumulate")
 
 
 def ctrl_advance(ctrl, d_counter, d_stamp, d_offset, offset_wrap):
@@ -311,9 +319,10 @@ def _rows(t, m, name):
 
 
 def linear_concat_fwd(a1, w1, a2=None, w2=None, bias=None, relu=False, m=None, m_dev=None,
-                      rows1=None, rows2=None, out=None):
+                      rows1=None, rows2=None, out=None, accumulate=False):
     """out = a1[rows1] @ w1^T + a2[rows2] @ w2^T (+bias)(relu)
-    (reference layers/sage.py:124-129; pool Linear :76,:202)."""
+    (reference layers/sage.py:124-129; pool Linear :76,:202).  accumulate=True: out += product
+    (out must be given and hold the addend; excludes bias / relu)."""
     lib = _lib.load()
     a1p, ld_a1 = _mat(a1, "a1")
     w1p, ld_w1 = _mat(w1, "w1")
@@ -342,6 +351,10 @@ def linear_concat_fwd(a1, w1, a2=None, w2=None, bias=None, relu=False, m=None, m
     if out.size(0) < m or out.size(1) != n:
         raise RuntimeError("linear_concat_fwd: bad output buffer")
     epi = (EPI_BIAS if bias is not None else 0) | (EPI_RELU if relu else 0)
+    if accumulate:
+        if epi:
+            raise RuntimeError("linear_concat_fwd: accumulate excludes bias / relu")
+        epi = EPI_ACCUM
     if bias is not None and bias.numel() != n:
         raise RuntimeError("linear_concat_fwd: bias length != n")
     rc = lib.sage_linear_concat_fwd(a1p, ld_a1, _rows(rows1, m, "rows1"), k1, w1p, ld_w1,
@@ -448,7 +461,8 @@ def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None):
     return y, (h if relu else None), inv_norm
 
 
-def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None):
+def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None, clear_dh=False):
+    """Backward of relu(normalize(z)).  clear_dh=True zeroes the consumed rows of dh."""
     lib = _lib.load()
     dp, ld_dh = _mat(dh, "dh")
     yp, ld_y = _mat(y, "y")
@@ -462,7 +476,7 @@ def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None):
         raise RuntimeError("l2norm_relu_bwd: bad buffers")
     rc = lib.sage_l2norm_relu_bwd(dp, ld_dh, yp, ld_y, _vec(inv_norm, torch.float32, "inv_norm"),
                                   1 if relu else 0, m, _count(m_dev, "m_dev"), n, zp, ld_dz,
-                                  _stream())
+                                  1 if clear_dh else 0, _stream())
     _lib.check(rc, "sage_l2norm_relu_bwd")
     return dz
 
@@ -500,9 +514,11 @@ def softmax_xent(logits, labels, label_rows=None, m=None, grad_scale=1.0, loss=N
     return loss, dlogits
 
 
-def logits_xent_fused(z, labels, label_rows, m, y, inv_norm, dz, row_loss, loss, grad_scale=1.0):
+def logits_xent_fused(z, labels, label_rows, m, y, inv_norm, dz, row_loss, loss, grad_scale=1.0,
+                      clear_z=False):
     """normalize + cross-entropy + gradient w.r.t. z in one pass (last layer of the step).
-    All buffers are caller-provided (static-shape engine); label_rows must be in range."""
+    All buffers are caller-provided (static-shape engine); label_rows must be in range.
+    clear_z=True zeroes the consumed rows of z (for a producer that accumulates into it)."""
     lib = _lib.load()
     zp, ld_z = _mat(z, "z")
     n = z.size(1)
@@ -520,13 +536,15 @@ def logits_xent_fused(z, labels, label_rows, m, y, inv_norm, dz, row_loss, loss,
                                     float(grad_scale), yp, ld_y,
                                     _vec(inv_norm, torch.float32, "inv_norm", allow_none=True), dp, ld_dz,
                                     _vec(row_loss, torch.float32, "row_loss"), _p(loss, torch.float32, "loss"),
-                                    _stream())
+                                    1 if clear_z else 0, _stream())
     _lib.check(rc, "sage_logits_xent_fused")
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8,
-              weight_decay=0.0, grad_scale=1.0):
-    """torch.optim.Adam step on flat fp32 buffers; step_dev (int64[1]) is advanced on device."""
+              weight_decay=0.0, grad_scale=1.0, step_out=None, zero_grad=False):
+    """torch.optim.Adam step on flat fp32 buffers.  The step count is read from step_dev
+    (int64[1]) and count+1 written to step_out (default: step_dev itself, which costs a second
+    tiny kernel).  zero_grad=True clears grad after use."""
     lib = _lib.load()
     n = param.numel()
     for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
@@ -536,7 +554,9 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
                             _p(exp_avg, torch.float32, "exp_avg"),
                             _p(exp_avg_sq, torch.float32, "exp_avg_sq"), n, float(lr), float(beta1),
                             float(beta2), float(eps), float(weight_decay), float(grad_scale),
-                            _count(step_dev, "step_dev"), _stream())
+                            _count(step_dev, "step_dev"),
+                            _count(step_dev if step_out is None else step_out, "step_out"),
+                            1 if zero_grad else 0, _stream())
     _lib.check(rc, "sage_adam_step")
 
 

@@ -53,6 +53,8 @@ typedef int64_t sage_i64;
 #define SAGE_EPI_NONE 0
 #define SAGE_EPI_BIAS 1 /* + bias[n]            (pool Linear, layers/sage.py:76)       */
 #define SAGE_EPI_RELU 2 /* relu                 (layers/sage.py:202,206)               */
+#define SAGE_EPI_ACCUM 4 /* out += product (alone): `out += lin_r(x_r)` of layers/sage.py:129; the
+                          * caller provides the addend (zeros for a plain product)        */
 
 /* words of the sampler's device state block (sage_i64 state[SAGE_STATE_WORDS]) */
 #define SAGE_ST_NODES 0      /* number of sampled nodes so far  (len(samples))           */
@@ -140,6 +142,11 @@ int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* row, sage_i6
                             size_t workspace_bytes, void* stream);
 int sage_ctrl_advance(sage_i64* ctrl_dev, sage_i64 d_counter, sage_i64 d_stamp, sage_i64 d_offset,
                       sage_i64 offset_wrap, void* stream);
+
+/* sum[0:SAGE_STATE_WORDS] += state[...]: running totals of the batch sizes the sampler
+ * reported (the device-side counterpart of `total_examples += batch.batch_size`,
+ * experiments/fig2a/runners/graphsage_runners.py:48, without reading the sizes back). */
+int sage_state_accumulate(const sage_i64* state, sage_i64* sum, void* stream);
 
 /* (f-2) one uniform random in-neighbour per start node; replaces
  * torch_cluster.random_walk(row, col, start, walk_length=1)[:,1] at samplers/utils.py:22.
@@ -271,9 +278,10 @@ int sage_l2norm_relu_fwd(const float* z, sage_i64 ld_z, sage_i64 m, const sage_i
 /* dz = (g - y * <y, g>) * inv_norm, with g = relu_mask ? dh * [y > 0] : dh.
  * Rows whose norm was clamped by eps (inv_norm == 1e12) get dz = g * inv_norm, the
  * gradient torch's clamp_min gives.  dz may alias dh. */
-int sage_l2norm_relu_bwd(const float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_y,
+int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_y,
                          const float* inv_norm, int relu_mask, sage_i64 m,
                          const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
+                         int clear_dh /* 1: dh rows are zeroed after use (consume-and-clear) */,
                          void* stream);
 
 /* Mean softmax cross-entropy over m rows and its gradient (F.cross_entropy of
@@ -291,17 +299,23 @@ int sage_softmax_xent(const float* logits, sage_i64 ld_logits, const sage_i64* l
  * row-local): y = normalize(z), loss = mean CE(y, labels), dz = d loss / d z (through the
  * soft-max and the normalisation).  row_loss[m] receives the per-row losses (workspace and
  * diagnostic), loss[0] their mean (fixed-order reduction).  y / inv_norm may be NULL. */
-int sage_logits_xent_fused(const float* z, sage_i64 ld_z, const sage_i64* labels,
+int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* labels,
                            const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
                            float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
-                           float* row_loss /*[m]*/, float* loss /*[1]*/, void* stream);
+                           float* row_loss /*[m]*/, float* loss /*[1]*/,
+                           int clear_z /* 1: z rows are zeroed after use */, void* stream);
 
 /* Adam (torch.optim.Adam defaults semantics, no amsgrad, L2 weight_decay added to the
- * gradient) on one flat parameter buffer.  step_dev: device int64 step counter,
- * incremented by the kernel (so a captured graph advances it on replay). */
-int sage_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+ * gradient) on one flat parameter buffer (optimizer.step() of
+ * experiments/fig2a/runners/graphsage_runners.py:45).  The step count t-1 is read from the
+ * device word step_in and t is written to step_out (so a captured graph advances it on
+ * replay); when the two are different words one kernel does both, when they are the same a
+ * second one-thread kernel bumps the counter.  zero_grad = 1 clears grad after use
+ * (optimizer.zero_grad() of :40 for the next step). */
+int sage_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    sage_i64 numel, float lr, float beta1, float beta2, float eps,
-                   float weight_decay, float grad_scale, sage_i64* step_dev, void* stream);
+                   float weight_decay, float grad_scale, const sage_i64* step_in,
+                   sage_i64* step_out, int zero_grad, void* stream);
 
 #ifdef __cplusplus
 }

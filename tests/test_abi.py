@@ -22,7 +22,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in sage_hip.h but not exported"
     assert set(_lib.SIGNATURES) == declared
     loaded = _lib.load()
-    assert loaded.sage_abi_version() == 1
+    assert loaded.sage_abi_version() == 2
     assert loaded.sage_last_error() is not None
 
 

@@ -25,7 +25,7 @@ def test_engine_matches_module_path(dev, aggregator):
     model_b = copy.deepcopy(model_a)
     graph = device_graph(data)
     engine = SageTrainEngine(model_b, NeighborSampler(data, [5, 3], seed=7), graph.features(data),
-                             graph.labels(data), B, lr=1e-2)
+                             graph.labels(data), B, lr=1e-2, keep_grads=True)
     opt = torch.optim.Adam(model_a.parameters(), lr=1e-2)
     for b, batch in enumerate(loader):
         opt.zero_grad()

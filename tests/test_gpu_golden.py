@@ -119,7 +119,7 @@ def test_engine_step_matches_golden(dev):
     graph = device_graph(data)
     B = len(s["seeds"])
     engine = SageTrainEngine(model, NeighborSampler(data, s["fanout"].tolist(), seed=int(s["rng_seed"])),
-                             graph.features(data), graph.labels(data), B, lr=float(g["lr"]))
+                             graph.features(data), graph.labels(data), B, lr=float(g["lr"]), keep_grads=True)
     loss = engine.step(torch.from_numpy(s["seeds"]).to(dev), counter=int(s["counter"]))
     nn = int(engine.buf.state[0])
     assert engine.buf.node[:nn].cpu().numpy().tolist() == s["node"].tolist()

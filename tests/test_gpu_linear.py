@@ -173,3 +173,59 @@ def test_linear_dweight2(dev, m, n, k1, k2):
     tol = 2e-4 * max(1.0, (m / 100) ** 0.5)
     torch.testing.assert_close(dw1.cpu(), dout[:h].t() @ a1[:h], rtol=RTOL, atol=tol)
     torch.testing.assert_close(dw2.cpu(), dout[:h].t() @ table[rows[:h]], rtol=RTOL, atol=tol)
+
+
+def test_fusion_flags(dev):
+    """Consume-and-clear / accumulate variants the engine uses to drop its fill kernels:
+    accumulate (out += product), clear_dh, clear_z, Adam with zero_grad and a separate step_out."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(3)
+    # out += a1 @ w1^T + a2 @ w2^T, small (split-K path) and large (tile path) outputs
+    for m, n, k in ((100, 41, 256), (700, 200, 96)):
+        a1, a2 = torch.randn(m, k, generator=g), torch.randn(m, k, generator=g)
+        w1, w2 = torch.randn(n, k, generator=g), torch.randn(n, k, generator=g)
+        base = torch.randn(m, n, generator=g)
+        out = base.clone().to(dev)
+        ops.linear_concat_fwd(a1.to(dev), w1.to(dev), a2.to(dev), w2.to(dev), out=out, accumulate=True)
+        torch.testing.assert_close(out.cpu(), base + a1 @ w1.t() + a2 @ w2.t(), rtol=1e-4, atol=1e-4)
+    with pytest.raises(RuntimeError):
+        ops.linear_concat_fwd(a1.to(dev), w1.to(dev), relu=True, out=out, accumulate=True)
+    # l2norm backward: same dz, dh rows below the device count cleared, the others untouched
+    m, n = 50, 24
+    z = torch.randn(m, n, generator=g).to(dev)
+    y, h, inv = ops.l2norm_relu_fwd(z, True)
+    dh = torch.randn(m, n, generator=g).to(dev)
+    want = ops.l2norm_relu_bwd(dh.clone(), y, inv, True)
+    dh2 = dh.clone()
+    cnt = torch.tensor([37], device=dev)
+    got = ops.l2norm_relu_bwd(dh2, y, inv, True, m_dev=cnt, clear_dh=True)
+    assert torch.equal(got[:37], want[:37])
+    assert float(dh2[:37].abs().max()) == 0.0 and torch.equal(dh2[37:], dh[37:])
+    # fused logits kernel: same outputs, z cleared
+    C, B = 7, 20
+    zz = torch.randn(B, C, generator=g).to(dev)
+    labels = torch.randint(0, C, (B,), generator=g).to(dev)
+    outs = []
+    for clear in (False, True):
+        zc = zz.clone()
+        yk, invk, dz = torch.empty(B, C, device=dev), torch.empty(B, device=dev), torch.empty(B, C, device=dev)
+        rl, loss = torch.empty(B, device=dev), torch.empty(1, device=dev)
+        ops.logits_xent_fused(zc, labels, None, B, yk, invk, dz, rl, loss, clear_z=clear)
+        outs.append((yk, invk, dz, rl, loss))
+        assert float(zc.abs().max()) == 0.0 if clear else torch.equal(zc, zz)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # Adam: ping-pong step words, gradient cleared; same parameters as the in-place form
+    n = 1000
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    pa, pb = p0.clone().to(dev), p0.clone().to(dev)
+    ma, va, mb, vb = (torch.zeros(n, device=dev) for _ in range(4))
+    step_a = torch.zeros(1, dtype=torch.int64, device=dev)
+    steps_b = torch.zeros(2, dtype=torch.int64, device=dev)
+    for it in range(3):
+        ga, gb = gr.clone().to(dev), gr.clone().to(dev)
+        ops.adam_step(pa, ga, ma, va, step_a, 1e-2)
+        par = it & 1
+        ops.adam_step(pb, gb, mb, vb, steps_b[par:par + 1], 1e-2, step_out=steps_b[1 - par:2 - par], zero_grad=True)
+        assert torch.equal(ga, gr.to(dev)) and float(gb.abs().max()) == 0.0
+    assert torch.equal(pa, pb) and int(step_a) == 3 and int(steps_b.max()) == 3
