@@ -40,6 +40,8 @@ SIGNATURES = {
                                        _P, c_int, c_int64, _P, c_int, _P, c_int64, _P]),
     "sage_linear_dinput": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int, c_int,
                                    _P, c_int64, c_int, _P]),
+    "sage_linear_dinput2": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64,
+                                    c_int64, _P, c_int, c_int, _P]),
     "sage_linear_dweight": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int, c_int,
                                     _P, c_int64, _P, _P]),
     "sage_linear_dweight2": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, c_int64,

@@ -535,6 +535,8 @@ struct SkinnyArgs {
   const float* bias;
   int epilogue;
   int accumulate;
+  float* out2;       // d-input pair: blockIdx.y == 1 multiplies by seg[1].b into out2
+  int64_t ld_out2;
 };
 
 __device__ inline float wave_sum64(float v) {
@@ -561,7 +563,9 @@ __global__ void __launch_bounds__(kThreads) skinny_dinput_kernel(SkinnyArgs s) {
   const int lane = threadIdx.x & 63;
   const int64_t m = static_cast<int64_t>(blockIdx.x) * (kThreads / 64) + (threadIdx.x >> 6);
   if (m >= m_lim) return;
-  const Segment& g = s.seg[0];       // a = dout [m][n], b = w [n][k]; g.k = n (contraction)
+  const Segment& g = s.seg[blockIdx.y];  // a = dout [m][n], b = w [n][k]; g.k = n (contraction)
+  float* const outp = blockIdx.y ? s.out2 : s.out;
+  const int64_t ld_outp = blockIdx.y ? s.ld_out2 : s.ld_out;
   const float* drow = g.a.p + m * g.a.ld;
   const int K = s.n;                 // output columns
   for (int k0 = lane * 4; k0 < K; k0 += 256) {
@@ -571,7 +575,7 @@ __global__ void __launch_bounds__(kThreads) skinny_dinput_kernel(SkinnyArgs s) {
       const float4 wv = *reinterpret_cast<const float4*>(g.b.p + n * g.b.ld + k0);
       acc.x += d * wv.x; acc.y += d * wv.y; acc.z += d * wv.z; acc.w += d * wv.w;
     }
-    float* o = s.out + m * s.ld_out + k0;
+    float* o = outp + m * ld_outp + k0;
     const float v[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -583,17 +587,37 @@ __global__ void __launch_bounds__(kThreads) skinny_dinput_kernel(SkinnyArgs s) {
 // dw[n][k] += sum_m dout[m][n] * a[rows(m)][k]  (n <= 64): thread per column k, block per
 // (256 columns, group of 8 output rows, slice of m); slices are combined with fp32 atomics
 constexpr int kDwRows = 8;
+struct SkinnyDwProblem {
+  const float* a;
+  int64_t ld_a;
+  const int64_t* rows;
+  int k;
+  float* dw;
+  int64_t ld_dw;
+};
+// blockIdx.z = problem * slices + slice of m: the two weight gradients of a layer (same dout)
+// run as one grid
 __global__ void __launch_bounds__(kThreads)
-skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ a,
-                      int64_t ld_a, const int64_t* __restrict__ rows, int64_t m,
-                      const int64_t* __restrict__ m_dev, int n, int k, int m_chunk,
-                      float* __restrict__ dw, int64_t ld_dw, float* __restrict__ dbias) {
+skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, SkinnyDwProblem p0,
+                      SkinnyDwProblem p1, int slices, int64_t m,
+                      const int64_t* __restrict__ m_dev, int n, int m_chunk,
+                      float* __restrict__ dbias) {
+  const int prob = blockIdx.z >= slices ? 1 : 0;
+  const SkinnyDwProblem& pr = prob ? p1 : p0;
+  const float* __restrict__ a = pr.a;
+  const int64_t ld_a = pr.ld_a;
+  const int64_t* __restrict__ rows = pr.rows;
+  const int k = pr.k;
+  float* __restrict__ dw = pr.dw;
+  const int64_t ld_dw = pr.ld_dw;
+  if (static_cast<int>(blockIdx.x) * kThreads >= k) return;
+  if (prob) dbias = nullptr;
   int64_t m_lim = m;
   if (m_dev != nullptr) {
     const int64_t v = *m_dev;
     if (v < m_lim) m_lim = v;
   }
-  const int64_t m_beg = static_cast<int64_t>(blockIdx.z) * m_chunk;
+  const int64_t m_beg = static_cast<int64_t>(blockIdx.z - prob * slices) * m_chunk;
   int64_t m_end = m_beg + m_chunk;
   if (m_end > m_lim) m_end = m_lim;
   if (m_beg >= m_end) return;
@@ -728,6 +752,35 @@ extern "C" int sage_linear_dinput(const float* dout, sage_i64 ld_dout, const flo
   return launch_gemm<true, false>(g, 1, stream, "gemm_kernel(dinput)");
 }
 
+extern "C" int sage_linear_dinput2(const float* dout, sage_i64 ld_dout, const float* w1,
+                                   sage_i64 ld_w1, float* da1, sage_i64 ld_da1, const float* w2,
+                                   sage_i64 ld_w2, float* da2, sage_i64 ld_da2, sage_i64 m,
+                                   const sage_i64* m_dev, int n, int k, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && k > 0 && ld_dout >= n && ld_w1 >= k && ld_w2 >= k && ld_da1 >= k &&
+                   ld_da2 >= k,
+               SAGE_EINVAL, "sage_linear_dinput2: bad shape (m=%lld n=%d k=%d)", (long long)m, n, k);
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(dout && w1 && w2 && da1 && da2, SAGE_EINVAL, "sage_linear_dinput2: NULL pointer argument");
+  if (n <= 64 && op_vec(w1, ld_w1, k) == 4 && op_vec(w2, ld_w2, k) == 4) {
+    SkinnyArgs s = {};
+    s.seg[0].a = {dout, ld_dout, nullptr, op_vec(dout, ld_dout, n)};
+    s.seg[0].b = {w1, ld_w1, nullptr, 4};
+    s.seg[0].k = n;
+    s.seg[1] = s.seg[0];
+    s.seg[1].b = {w2, ld_w2, nullptr, 4};
+    s.nseg = 2;
+    s.m = m; s.m_dev = m_dev; s.n = k; s.out = da1; s.ld_out = ld_da1; s.out2 = da2; s.ld_out2 = ld_da2;
+    dim3 grid(static_cast<unsigned>(cdiv(m, kThreads / 64)), 2);
+    skinny_dinput_kernel<<<grid, kThreads, 0, stream>>>(s);
+    SAGE_CHECK_LAUNCH("skinny_dinput_kernel(pair)");
+    return SAGE_OK;
+  }
+  int rc = sage_linear_dinput(dout, ld_dout, w1, ld_w1, m, m_dev, n, k, da1, ld_da1, 0, stream_);
+  if (rc != SAGE_OK) return rc;
+  return sage_linear_dinput(dout, ld_dout, w2, ld_w2, m, m_dev, n, k, da2, ld_da2, 0, stream_);
+}
+
 extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const float* a,
                                    sage_i64 ld_a, const sage_i64* rows, sage_i64 m,
                                    const sage_i64* m_dev, int n, int k, float* dw, sage_i64 ld_dw,
@@ -757,10 +810,12 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
     if (sp > 16) sp = 16;
     if (sp < 1) sp = 1;
     const int m_chunk = static_cast<int>(cdiv(m, sp));
+    const int slices = static_cast<int>(cdiv(m, m_chunk));
     dim3 grid(static_cast<unsigned>(col_blocks), static_cast<unsigned>(cdiv(n, kDwRows)),
-              static_cast<unsigned>(cdiv(m, m_chunk)));
-    skinny_dweight_kernel<<<grid, kThreads, 0, stream>>>(dout, ld_dout, a, ld_a, rows, m, m_dev, n, k,
-                                                         m_chunk, dw, ld_dw, dbias);
+              static_cast<unsigned>(slices));
+    const SkinnyDwProblem p0 = {a, ld_a, rows, k, dw, ld_dw};
+    skinny_dweight_kernel<<<grid, kThreads, 0, stream>>>(dout, ld_dout, p0, p0, slices, m, m_dev, n,
+                                                         m_chunk, dbias);
     SAGE_CHECK_LAUNCH("skinny_dweight_kernel");
     return SAGE_OK;
   }
@@ -788,7 +843,23 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
   SAGE_REQUIRE(m < (1ll << 31), SAGE_ELIMIT, "sage_linear_dweight2: m too large");
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(dout && a1 && a2 && dw1 && dw2, SAGE_EINVAL, "sage_linear_dweight2: NULL pointer argument");
-  if (n <= 64 || k1 <= 64 || k2 <= 64) {  // skinny shapes: the single-problem paths are better
+  if (n <= 64) {  // skinny: both problems in one VALU grid
+    const int kmax = k1 > k2 ? k1 : k2;
+    int64_t sp = cdiv(m, 32);       // >= 32 rows of m per block, <= 16 slices (atomic contention)
+    if (sp > 16) sp = 16;
+    if (sp < 1) sp = 1;
+    const int m_chunk = static_cast<int>(cdiv(m, sp));
+    const int slices = static_cast<int>(cdiv(m, m_chunk));
+    dim3 grid(static_cast<unsigned>(cdiv(kmax, kThreads)), static_cast<unsigned>(cdiv(n, kDwRows)),
+              static_cast<unsigned>(2 * slices));
+    const SkinnyDwProblem p0 = {a1, ld_a1, rows1, k1, dw1, ld_dw1};
+    const SkinnyDwProblem p1 = {a2, ld_a2, rows2, k2, dw2, ld_dw2};
+    skinny_dweight_kernel<<<grid, kThreads, 0, stream>>>(dout, ld_dout, p0, p1, slices, m, m_dev, n,
+                                                         m_chunk, nullptr);
+    SAGE_CHECK_LAUNCH("skinny_dweight_kernel(pair)");
+    return SAGE_OK;
+  }
+  if (k1 <= 64 || k2 <= 64) {  // narrow inputs: the single-problem tile shapes are better
     int rc = sage_linear_dweight(dout, ld_dout, a1, ld_a1, rows1, m, m_dev, n, k1, dw1, ld_dw1, nullptr, stream_);
     if (rc != SAGE_OK) return rc;
     return sage_linear_dweight(dout, ld_dout, a2, ld_a2, rows2, m, m_dev, n, k2, dw2, ld_dw2, nullptr, stream_);

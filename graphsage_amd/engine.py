@@ -296,8 +296,8 @@ class SageTrainEngine:
                                 x_in, self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
             if i > 0:
                 prev = self.act[i - 1]
-                lib.linear_dinput(a['dz'], layer.lin_r.weight, m=t_cap, m_dev=t_dev, out=prev['dh'])
-                lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
+                lib.linear_dinput2(a['dz'], layer.lin_r.weight, prev['dh'], layer.lin_l.weight, a['dagg'],
+                                   m=t_cap, m_dev=t_dev)
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       num_targets_dev=t_dev)
 

@@ -387,6 +387,24 @@ def linear_dinput(dout, w, m=None, m_dev=None, out=None, accumulate=False):
     return out
 
 
+def linear_dinput2(dout, w1, out1, w2, out2, m=None, m_dev=None):
+    """out1 = dout @ w1, out2 = dout @ w2 in one launch (both overwritten)."""
+    lib = _lib.load()
+    dp, ld_d = _mat(dout, "dout")
+    w1p, ld_w1 = _mat(w1, "w1")
+    w2p, ld_w2 = _mat(w2, "w2")
+    o1p, ld_o1 = _mat(out1, "out1")
+    o2p, ld_o2 = _mat(out2, "out2")
+    n, k = w1.shape
+    m = dout.size(0) if m is None else int(m)
+    if tuple(w2.shape) != (n, k) or dout.size(1) != n or dout.size(0) < m or \
+            out1.size(0) < m or out2.size(0) < m or out1.size(1) != k or out2.size(1) != k:
+        raise RuntimeError("linear_dinput2: shape mismatch")
+    rc = lib.sage_linear_dinput2(dp, ld_d, w1p, ld_w1, o1p, ld_o1, w2p, ld_w2, o2p, ld_o2, m,
+                                 _count(m_dev, "m_dev"), n, k, _stream())
+    _lib.check(rc, "sage_linear_dinput2")
+
+
 def linear_dweight(dout, a, m=None, m_dev=None, rows=None, dw=None, dbias=None):
     """dw += dout^T @ a[rows]  (dw is [n, k]; zero-initialised if not given)."""
     lib = _lib.load()

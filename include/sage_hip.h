@@ -228,6 +228,14 @@ int sage_linear_dinput(const float* dout, sage_i64 ld_dout, const float* w, sage
                        sage_i64 m, const sage_i64* m_dev, int n, int k, float* da,
                        sage_i64 ld_da, int accumulate, void* stream);
 
+/* Both input gradients of a layer in one launch: da1 = dout . w1, da2 = dout . w2 (what autograd
+ * derives for out = lin_l(agg) + lin_r(x_r), layers/sage.py:124-129: d agg and d x_r).  Same
+ * shapes as sage_linear_dinput; both outputs are overwritten. */
+int sage_linear_dinput2(const float* dout, sage_i64 ld_dout, const float* w1, sage_i64 ld_w1,
+                        float* da1, sage_i64 ld_da1, const float* w2, sage_i64 ld_w2, float* da2,
+                        sage_i64 ld_da2, sage_i64 m, const sage_i64* m_dev, int n, int k,
+                        void* stream);
+
 /* Weight gradient: dw[n, k] = sum_m dout[m, n] * a[r(m), k]  (dw = dout^T @ a), split
  * over m across workgroups and combined with fp32 atomics into dw, which must be
  * pre-initialised (zero, or a gradient to accumulate into).  dbias[n] = sum_m dout[m,n]

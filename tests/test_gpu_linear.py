@@ -156,7 +156,8 @@ def test_logits_xent_fused_matches_three_kernels(dev):
     torch.testing.assert_close(row_loss.cpu(), ref_rows, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("m,n,k1,k2", [(3000, 256, 602, 602), (700, 96, 130, 300), (512, 41, 256, 256)])
+@pytest.mark.parametrize("m,n,k1,k2", [(3000, 256, 602, 602), (700, 96, 130, 300), (512, 41, 256, 256),
+                                       (300, 7, 100, 520), (90, 200, 40, 300)])
 def test_linear_dweight2(dev, m, n, k1, k2):
     from graphsage_amd import ops
     g = torch.Generator().manual_seed(m)
@@ -173,6 +174,21 @@ def test_linear_dweight2(dev, m, n, k1, k2):
     tol = 2e-4 * max(1.0, (m / 100) ** 0.5)
     torch.testing.assert_close(dw1.cpu(), dout[:h].t() @ a1[:h], rtol=RTOL, atol=tol)
     torch.testing.assert_close(dw2.cpu(), dout[:h].t() @ table[rows[:h]], rtol=RTOL, atol=tol)
+
+
+@pytest.mark.parametrize("m,n,k", [(512, 41, 256), (100, 7, 36), (300, 200, 128), (65, 64, 600)])
+def test_linear_dinput2(dev, m, n, k):
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m + k)
+    dout, w1, w2 = _rand((m, n), g), _rand((n, k), g), _rand((n, k), g)
+    o1 = torch.full((m + 5, k), 7.0, device=dev)
+    o2 = torch.full((m + 5, k), 7.0, device=dev)
+    mdev = torch.tensor([m - 9], device=dev)
+    ops.linear_dinput2(dout.to(dev), w1.to(dev), o1, w2.to(dev), o2, m=m, m_dev=mdev)
+    h = m - 9
+    torch.testing.assert_close(o1[:h].cpu(), dout[:h] @ w1, rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(o2[:h].cpu(), dout[:h] @ w2, rtol=RTOL, atol=ATOL)
+    assert bool((o1[h:] == 7.0).all()) and bool((o2[h:] == 7.0).all())
 
 
 def test_fusion_flags(dev):
