@@ -9,7 +9,7 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsage_hip.so")
+LIB_PATH = os.environ.get("SAGE_HIP_LIB") or os.path.join(_HERE, "libsage_hip.so")   # override: A/B builds
 
 # name -> (restype, argtypes); mirrors include/sage_hip.h declaration by declaration.
 _P = c_void_p

@@ -93,8 +93,8 @@ struct TileLoader {
 
   VT v[2][PASSES];            // two register sets: the loads of two K-steps are in flight
   int64_t rowoff[PASSES];     // KC: offset of the (clamped, mapped) row in floats from op.p
-  bool rvalid[PASSES];        // KC: row below the limit
-  int64_t rows[PASSES];       // !KC: (mapped) row ids of the K-step issued next
+  int rows[PASSES];           // !KC: (mapped) row ids of the K-step issued next (< 2^31)
+  int64_t coff[PASSES];       // !KC: clamped column offset of the pass
   Operand op;
   int64_t mn0, mn_lim;
   int k_end;
@@ -102,6 +102,9 @@ struct TileLoader {
   __device__ inline int trow(int p) const { return (threadIdx.x + p * kThreads) / UPR; }
   __device__ inline int tcol(int p) const { return ((threadIdx.x + p * kThreads) % UPR) * VEC; }
 
+  // Rows / columns of the NON-contracted dimension beyond the limit are clamped to valid
+  // addresses and NOT zeroed: they only feed output rows / columns that the epilogue does not
+  // store.  Only the tail of the contraction is zeroed (store_pass).
   __device__ inline void begin(const Operand& o, int64_t mn0_, int64_t mn_lim_, int k_beg, int k_end_) {
     op = o; mn0 = mn0_; mn_lim = mn_lim_; k_end = k_end_;
     // all row-map lookups are issued back to back (clamped indices, no branch between them)
@@ -120,17 +123,18 @@ struct TileLoader {
     for (int p = 0; p < PASSES; ++p) {
       if (KC) {
         rowoff[p] = ids[p] * op.ld;
-        rvalid[p] = mn0 + trow(p) < mn_lim;
       } else {
-        rows[p] = ids[p];
+        rows[p] = static_cast<int>(ids[p]);
+        const int64_t cmax = (mn_lim - 1) / VEC * VEC;
+        const int64_t c = mn0 + tcol(p);
+        coff[p] = c < cmax ? c : cmax;
       }
     }
   }
 
   // Request pass p of the tile whose first contraction index is k0.  The load is
-  // UNCONDITIONAL: rows and columns beyond the limits are clamped to the last valid vector of
-  // the operand and zeroed in store_pass().  Straight-line loads (no exec-masked branches) let
-  // the compiler count vmcnt exactly, so the store of one register set does not wait for the
+  // UNCONDITIONAL (clamped address).  Straight-line loads (no exec-masked branches) let the
+  // compiler count vmcnt exactly, so the store of one register set does not wait for the
   // younger set.  Safe for any k0; passes must be issued for consecutive K-steps.
   template <int SET>
   __device__ inline void issue_pass(int p, int k0) {
@@ -141,16 +145,14 @@ struct TileLoader {
       const int kk = k0 + tcol(p);
       src = op.p + rowoff[p] + (kk < kmax ? kk : kmax);
     } else {
-      const int64_t cmax = (mn_lim - 1) / VEC * VEC;
-      const int64_t c = mn0 + tcol(p);
-      src = op.p + rows[p] * op.ld + (c < cmax ? c : cmax);
+      src = op.p + static_cast<int64_t>(rows[p]) * op.ld + coff[p];   // one 32x32->64 multiply-add
     }
     v[SET][p] = *((GlobalVec)(src));
     if (!KC) {
       // row id of the NEXT K-step; it arrives while this step's data is in flight
-      const int64_t r = static_cast<int64_t>(k0) + BK + trow(p);
-      rows[p] = r < k_end ? r : static_cast<int64_t>(k_end) - 1;
-      if (op.rowmap != nullptr) rows[p] = op.rowmap[rows[p]];
+      const int r = k0 + BK + trow(p);
+      const int rc = r < k_end ? r : k_end - 1;
+      rows[p] = op.rowmap != nullptr ? static_cast<int>(op.rowmap[rc]) : rc;
     }
   }
   template <int SET>
@@ -159,21 +161,28 @@ struct TileLoader {
     for (int p = 0; p < PASSES; ++p) issue_pass<SET>(p, k0);
   }
 
-  // write pass p of the tile requested by issue(k0) into LDS
-  template <int LDS_LD, int SET>
+  // write pass p of the tile requested by issue(k0) into LDS.  TAIL = false: the step lies
+  // entirely below k_end, nothing to zero.
+  template <int LDS_LD, int SET, bool TAIL = true>
   __device__ inline void store_pass(int p, int k0, float* lds) const {
     float e[VEC];
     if constexpr (VEC == 4) { e[0] = v[SET][p].x; e[1] = v[SET][p].y; e[2] = v[SET][p].z; e[3] = v[SET][p].w; }
     else if constexpr (VEC == 2) { e[0] = v[SET][p].x; e[1] = v[SET][p].y; }
     else { e[0] = v[SET][p]; }
-    // zero what lies beyond the limits: whole vectors of clamped rows / columns, and the tail
-    // of a ragged last vector (it may have read row padding)
-    const int64_t c0 = KC ? static_cast<int64_t>(k0 + tcol(p)) : (mn0 + tcol(p));
-    const int64_t c_lim = KC ? static_cast<int64_t>(k_end) : mn_lim;
-    const bool row_ok = KC ? rvalid[p] : (k0 + trow(p) < k_end);
+    if constexpr (TAIL) {
+      if (KC) {
+        const int c0 = k0 + tcol(p);
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      if (!row_ok || c0 + j >= c_lim) e[j] = 0.f;
+        for (int j = 0; j < VEC; ++j) {
+          if (c0 + j >= k_end) e[j] = 0.f;
+        }
+      } else {
+        const bool row_ok = k0 + trow(p) < k_end;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (!row_ok) e[j] = 0.f;
+        }
+      }
     }
     // both layouts keep the loaded vector contiguous: [mn][k] for KC, [k][mn] otherwise
     float* dst = lds + trow(p) * LDS_LD + tcol(p);
@@ -185,10 +194,10 @@ struct TileLoader {
       for (int j = 0; j < VEC; ++j) dst[j] = e[j];
     }
   }
-  template <int LDS_LD, int SET>
+  template <int LDS_LD, int SET, bool TAIL = true>
   __device__ inline void store(int k0, float* lds) const {
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) store_pass<LDS_LD, SET>(p, k0, lds);
+    for (int p = 0; p < PASSES; ++p) store_pass<LDS_LD, SET, TAIL>(p, k0, lds);
   }
 };
 
@@ -196,6 +205,13 @@ struct TileLoader {
 template <bool A_KC, bool B_KC, int BM, int BN, int VEC>
 __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / 64, TN = BN / 64;
+  // n-contiguous B with an even number of column tiles per wave: the tiles are interleaved in
+  // pairs so that one 8-byte LDS read serves two MFMAs (see the K-loop); ncol() is the map
+#ifdef SAGE_NO_PAIRN
+  constexpr bool kPairN = false;
+#else
+  constexpr bool kPairN = !B_KC && (TN % 2 == 0);
+#endif
   // row stride and size of one LDS buffer per operand: [BM][BK+4] (k contiguous) or [BK][BM+4]
   constexpr int LDA = A_KC ? BK + 4 : BM + 4;
   constexpr int LDB = B_KC ? BK + 4 : BN + 4;
@@ -230,6 +246,9 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   const int wn0 = (wave & 1) * (BN / 2);
   const int l31 = lane & 31;
   const int half = lane >> 5;
+  auto ncol = [&](int j) -> int {   // tile-local column of accumulator tile j held by this lane
+    return wn0 + j * 32 + l31;      // (after the epilogue's un-interleave when kPairN)
+  };
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -394,6 +413,18 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
             if constexpr (B_KC) {
               const f4v v = *reinterpret_cast<const f4v*>(bs + (wn0 + jn * 32 + l31) * LDB + g8 + 4 * half);
               bf[jn][0] = v[0]; bf[jn][1] = v[1]; bf[jn][2] = v[2]; bf[jn][3] = v[3];
+            } else if constexpr (kPairN) {
+              // column tiles jn, jn+1 interleaved (n = 64*(jn/2) + 2*lane + (jn&1)): one
+              // ds_read_b64 per k feeds both (142 vs 125 TF/s LDS-fed, scratch/lds_mfma.hip)
+              if ((jn & 1) == 0) {
+                typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  const f2v v = *reinterpret_cast<const f2v*>(bs + (g8 + 4 * half + j) * LDB + wn0 + jn * 32 + 2 * l31);
+                  bf[jn][j] = v[0];
+                  bf[jn + 1][j] = v[1];
+                }
+              }
             } else {
 #pragma unroll
               for (int j = 0; j < 4; ++j) bf[jn][j] = bs[(g8 + 4 * half + j) * LDB + wn0 + jn * 32 + l31];
@@ -411,7 +442,10 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
             }
           }
         }
-        if (has_next) {
+        if (k0 + 2 * BK <= k_end) {          // the next step is a full one: nothing to zero
+          la.template store<LDA, 0, false>(k0 + BK, As + (cur ^ 1) * ASZ);
+          lb.template store<LDB, 0, false>(k0 + BK, Bs + (cur ^ 1) * BSZ);
+        } else if (has_next) {
           la.template store<LDA, 0>(k0 + BK, As + (cur ^ 1) * ASZ);
           lb.template store<LDB, 0>(k0 + BK, Bs + (cur ^ 1) * BSZ);
         }
@@ -421,12 +455,34 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
     }
   }
 
+  if constexpr (kPairN) {
+    // The K-loop computed column tiles (j, j+1) interleaved: lane c holds columns 2c and 2c+1
+    // of the 64-column pair.  Give every lane columns c and 32+c instead (4 lane shuffles per
+    // accumulator register), so that the stores / atomics below stay 128-byte contiguous.
+    const int s0 = (lane & 32) | (l31 >> 1), s1 = s0 + 16;
+    const bool odd = (l31 & 1) != 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; j += 2) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float x0 = acc[i][j][e], x1 = acc[i][j + 1][e];
+          const float a0 = __shfl(x0, s0), a1 = __shfl(x1, s0);
+          const float b0 = __shfl(x0, s1), b1 = __shfl(x1, s1);
+          acc[i][j][e] = odd ? a1 : a0;
+          acc[i][j + 1][e] = odd ? b1 : b0;
+        }
+      }
+    }
+  }
+
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3)+8*(e>>2)+4*half
   const bool relu = (g.epilogue & SAGE_EPI_RELU) != 0;
   float bv[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int64_t col = n0 + wn0 + j * 32 + l31;
+    const int64_t col = n0 + ncol(j);
     bv[j] = ((g.epilogue & SAGE_EPI_BIAS) && col < n_lim) ? g.bias[col] : 0.f;
     // consume the load here so that the stores below do not each wait on vmcnt(0)
     asm volatile("" : "+v"(bv[j]));
@@ -435,7 +491,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int64_t col = n0 + wn0 + j * 32 + l31;
+      const int64_t col = n0 + ncol(j);
       const int64_t row0 = m0 + wm0 + i * 32 + 4 * half;
       float* base = out_p + row0 * ld_out_p + col;
       if (g.atomic_out) {  // block-uniform

@@ -10,10 +10,11 @@ constexpr int BK = 32, BM = 64, BN = 128;
 
 // V=1: k-major As[k][m], ds_read_b32 per operand (current kernel)
 // V=2: m-major As[m][k] (row stride 36), ds_read_b128: lane half h takes k = 8g + 4h .. +3
+// V=3: k-major, A ds_read_b32, B one ds_read_b64 per k: the wave's two column tiles interleaved (n = 2c + j)
 template <int V, bool BARRIER>
 __global__ void __launch_bounds__(256, 2) k(const float* in, float* out, int ksteps) {
-  constexpr int LDA = V == 1 ? BM + 2 : BK + 4, LDB = V == 1 ? BN + 2 : BK + 4;
-  constexpr int ASZ = V == 1 ? BK * LDA : BM * LDA, BSZ = V == 1 ? BK * LDB : BN * LDB;
+  constexpr int LDA = V == 2 ? BK + 4 : BM + (V == 1 ? 2 : 4), LDB = V == 2 ? BK + 4 : BN + (V == 1 ? 2 : 4);
+  constexpr int ASZ = V == 2 ? BM * LDA : BK * LDA, BSZ = V == 2 ? BN * LDB : BK * LDB;
   __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
   for (int i = threadIdx.x; i < 2 * (ASZ + BSZ); i += 256) lds[i] = in[(blockIdx.x * 977 + i) & 0xFFFFF];
   __syncthreads();
@@ -32,6 +33,15 @@ __global__ void __launch_bounds__(256, 2) k(const float* in, float* out, int kst
         const float b1 = bs[(2 * p + half) * LDB + wn0 + 32 + l31];
         c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, c1, 0, 0, 0);
+      }
+    } else if (V == 3) {
+      typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int p = 0; p < 16; ++p) {
+        const float a = as[(2 * p + half) * LDA + wm0 + l31];
+        const f2v b = *reinterpret_cast<const f2v*>(bs + (2 * p + half) * LDB + wn0 + 2 * l31);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[1], c1, 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -78,6 +88,8 @@ int main() {
   if (hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice) != hipSuccess) return 1;
   run<1, true>(in, out, "k-major b32 reads, barrier");
   run<1, false>(in, out, "k-major b32 reads, no barrier");
+  run<3, true>(in, out, "k-major A b32 + B b64, barrier");
+  run<3, false>(in, out, "k-major A b32 + B b64, no barrier");
   run<2, true>(in, out, "m-major b128 reads, barrier");
   run<2, false>(in, out, "m-major b128 reads, no barrier");
   return 0;
