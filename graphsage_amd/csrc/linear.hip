@@ -685,7 +685,7 @@ skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, SkinnyDwP
   float acc[kDwRows];
 #pragma unroll
   for (int i = 0; i < kDwRows; ++i) acc[i] = 0.f;
-  constexpr int U = 4;  // rows of m in flight
+  constexpr int U = 16;  // rows of m in flight (the slice is latency-bound: 2 round trips, not 8)
   for (int64_t mm = m_beg; mm < m_end; mm += U) {
     float av[U];
     int64_t mc[U];
