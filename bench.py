@@ -159,13 +159,15 @@ def main():
             else:
                 engine.replay()
     else:
-        # same pipeline driven eagerly: sampler of step s+1 on the side stream during step s
-        engine.prefetch(seeds_of(0), counter_of(0))
+        # same pipeline driven eagerly: the sampler runs engine.depth batches ahead on the side stream
+        depth = engine.depth
+        for d in range(depth):
+            engine.prefetch(seeds_of(d), counter_of(d))
 
         def run_step(s, timed):
             b = (lambda: ev[cur["i"]][0].record()) if (probe and timed) else None
             a = (lambda: ev[cur["i"]][1].record()) if (probe and timed) else None
-            engine.pipelined_step(seeds_of(s + 1), counter_of(s + 1), b, a)
+            engine.pipelined_step(seeds_of(s + depth), counter_of(s + depth), b, a)
 
     for s in range(args.warmup):
         run_step(s, False)

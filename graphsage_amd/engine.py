@@ -103,8 +103,12 @@ class SageTrainEngine:
         # the engine owns its sampler state (relabel table, stamps, buffers): a replayed graph
         # advances the stamp on the device, so the table cannot be shared with eager callers
         self.table = ops.new_relabel_table(self.graph.num_nodes, dev)
+        # sample-buffer slots: batch i computes from one while the sampler fills the next; with
+        # overlap_gather a third one, because then the sampler runs TWO batches ahead
+        self.overlap_gather = bool(overlap_gather)
+        self.nslots = 3 if self.overlap_gather else 2
         self.bufs = [ops.SampleBuffers(self.graph.num_nodes, self.hop_cap[-1], edge_cap, dev)
-                     for _ in range(2)]
+                     for _ in range(self.nslots)]
         self.ctrl = torch.zeros(ops.CTRL_WORDS, dtype=torch.int64, device=dev)
         self._stamp = 0
         # device-side row counts per slot: n_dev[slot][h] = #nodes after hop h
@@ -144,10 +148,12 @@ class SageTrainEngine:
                 a['dagg'] = padded(t_cap, fin)
             self.act.append(a)
         # layer-0 aggregate per sample slot: with overlap_gather the HBM-bound gather of batch i+1
-        # runs on the side stream (it needs no weights) beside the MFMA-bound backward of batch i
-        self.overlap_gather = bool(overlap_gather)
-        self.agg0 = [self.act[0]['agg'],
-                     padded(self.act[0]['t_cap'], self.act[0]['fin']) if overlap_gather else self.act[0]['agg']]
+        # runs on the side stream (it needs no weights) beside the MFMA-bound forward GEMM of
+        # batch i, into a buffer of its own
+        self.agg0 = [self.act[0]['agg']] * self.nslots
+        if self.overlap_gather:
+            self.agg0 = [self.act[0]['agg']] + [padded(self.act[0]['t_cap'], self.act[0]['fin'])
+                                                 for _ in range(self.nslots - 1)]
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.row_loss = torch.zeros(self.B, dtype=torch.float32, device=dev)
         # running sums of the sampler's state block over computed batches (batch sizes; a non-zero
@@ -158,10 +164,24 @@ class SageTrainEngine:
         self._tapes = {}        # recorded C-ABI call sequences, keyed by (what, slot, ..., stream)
         # pipelining state
         self.side = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event(), torch.cuda.Event()]      # slot sampled
-        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]   # slot's compute finished
-        self.use = 0            # slot the next compute reads
-        self.primed = False
+        self.ready = [torch.cuda.Event() for _ in range(self.nslots)]      # slot ready for compute
+        self.consumed = [torch.cuda.Event() for _ in range(self.nslots)]   # slot's compute finished
+        self.started = torch.cuda.Event()    # main stream reached the start of a step
+        self.queue = []         # slots sampled and not yet computed, oldest first
+        self.gathered = [False] * self.nslots   # overlap_gather: slot's layer-0 aggregate is done
+        self.used = [False] * self.nslots       # slot has been computed from at least once
+        self.next_slot = 0
+        self.use = 0            # graph replay: slot the next compute reads
+
+    @property
+    def primed(self):
+        return bool(self.queue)
+
+    @property
+    def depth(self):
+        """How many batches ahead of the one being computed the sampler runs: callers prime the
+        pipeline with `depth` prefetch() calls and hand pipelined_step() batch i + depth."""
+        return self.nslots - 1
 
     @property
     def step_dev(self):
@@ -212,20 +232,26 @@ class SageTrainEngine:
         _lib.check(fn(*args), name)
         _lib.check(acc[0](*acc[1]), acc[2])      # state_sum += this batch's sizes, same stream
 
-    def _taped(self, what, slot, fn):
+    def _taped(self, what, slot, fn, stream=None):
         """Run fn() through the validating wrappers once per (what, slot, stream) and replay the
-        recorded C-ABI calls afterwards: every pointer the engine passes is static."""
-        key = (what, slot, torch.cuda.current_stream().cuda_stream)
+        recorded C-ABI calls afterwards: every pointer the engine passes is static.  `stream`
+        (default: the current one) is where the calls go; a replay needs no stream switch."""
+        cur = torch.cuda.current_stream()
+        key = (what, slot, (stream or cur).cuda_stream)
         tape = self._tapes.get(key)
         if tape is None:
-            with _lib.recording() as tape:
-                fn()
+            if stream is not None and stream != cur:
+                with torch.cuda.stream(stream), _lib.recording() as tape:
+                    fn()
+            else:
+                with _lib.recording() as tape:
+                    fn()
             self._tapes[key] = tape
         else:
             _lib.replay(tape)
 
-    def gather_layer0(self, slot=0):
-        self._taped('gather0', slot, lambda: self._gather_layer0(slot))
+    def gather_layer0(self, slot=0, stream=None):
+        self._taped('gather0', slot, lambda: self._gather_layer0(slot), stream)
 
     def _gather_layer0(self, slot):
         a, buf = self.act[0], self.bufs[slot]
@@ -333,48 +359,75 @@ class SageTrainEngine:
         return self.loss
 
     # ------------------------------------------------------------------ pipelined, eager
-    def prefetch(self, seeds, counter, before_gather=None, after_gather=None):
-        """Sample `seeds` on the side stream into the slot the next-but-one compute will read
-        (and, with overlap_gather, run that batch's layer-0 gather there too)."""
-        slot = self.use if not self.primed else 1 - self.use
-        main = torch.cuda.current_stream()
-        self.side.wait_stream(main) if not self.primed else self.side.wait_event(self.consumed[slot])
-        self.sample(seeds, counter, slot=slot, stream=self.side)
-        if self.overlap_gather:
+    def _side_gather(self, slot, before_gather, after_gather):
+        if before_gather is None and after_gather is None:
+            self.gather_layer0(slot, stream=self.side)
+        else:     # the hooks record events on the current stream
             with torch.cuda.stream(self.side):
                 if before_gather is not None:
                     before_gather()
                 self.gather_layer0(slot)
                 if after_gather is not None:
                     after_gather()
-        self.ready[slot].record(self.side)
+        self.gathered[slot] = True
+
+    def prefetch(self, seeds, counter, before_gather=None, after_gather=None):
+        """Sample `seeds` on the side stream into the next free slot.  Call it `depth` times
+        before the first pipelined_step()."""
+        if len(self.queue) >= self.depth:
+            raise RuntimeError("prefetch(): the pipeline is full")
+        slot = self.next_slot
+        self.next_slot = (slot + 1) % self.nslots
+        main = torch.cuda.current_stream()
+        if self.used[slot]:
+            self.side.wait_event(self.consumed[slot])
+        else:
+            self.side.wait_stream(main)
+        self.sample(seeds, counter, slot=slot, stream=self.side)
         seeds.record_stream(self.side)
-        self.primed = True
+        self.gathered[slot] = False
+        self.queue.append(slot)
+        if not self.overlap_gather:
+            self.ready[slot].record(self.side)
+        elif len(self.queue) == 1:
+            # nothing is computing: no GEMM to hide behind, gather right away
+            self._side_gather(slot, before_gather, after_gather)
+            self.ready[slot].record(self.side)
 
     def pipelined_step(self, next_seeds=None, next_counter=None, before_gather=None, after_gather=None):
-        """Train on the prefetched batch while the sampler of the next one runs beside it."""
-        if not self.primed:
+        """Train on the oldest prefetched batch while the side stream prepares the following ones:
+        the sampler of batch i+depth and, with overlap_gather, the layer-0 gather of batch i+1
+        (held back until this step has started, so that it runs beside the forward GEMM)."""
+        if not self.queue:
             raise RuntimeError("pipelined_step() needs a prefetch() first")
-        p = self.use
+        p = self.queue[0]
         ov = self.overlap_gather
-        if next_seeds is not None:
-            self.prefetch(next_seeds, next_counter, before_gather if ov else None, after_gather if ov else None)
         main = torch.cuda.current_stream()
+        if ov and not self.gathered[p]:      # pipeline was drained below its depth
+            self._side_gather(p, None, None)
+            self.ready[p].record(self.side)
         main.wait_event(self.ready[p])
-        if not ov:
+        if ov:
+            if len(self.queue) > 1:
+                self.started.record(main)
+                self.side.wait_event(self.started)
+                q = self.queue[1]
+                self._side_gather(q, before_gather, after_gather)
+                self.ready[q].record(self.side)
+        else:
             if before_gather is not None:
                 before_gather()
             self.gather_layer0(p)
             if after_gather is not None:
                 after_gather()
+        self.queue.pop(0)
+        if next_seeds is not None:
+            self.prefetch(next_seeds, next_counter)
         self.forward_backward(slot=p, skip_gather0=True)
         self.all_reduce()
         self.optimizer_step()
         self.consumed[p].record(main)
-        if next_seeds is None:
-            self.primed = False
-        else:
-            self.use = 1 - p
+        self.used[p] = True
         return self.loss
 
     # ------------------------------------------------------------------ epochs and evaluation
@@ -392,10 +445,12 @@ class SageTrainEngine:
 
         def counter(b):
             return batch_counter(epoch, nb, b, rank, self.world_size)
-        self.prefetch(seeds[:self.B], counter(0))
+        d = self.depth
+        for b in range(min(d, nb)):
+            self.prefetch(seeds[b * self.B:(b + 1) * self.B], counter(b))
         for b in range(nb):
-            nxt = seeds[(b + 1) * self.B:(b + 2) * self.B] if b + 1 < nb else None
-            loss = self.pipelined_step(nxt, counter(b + 1) if nxt is not None else None)
+            nxt = seeds[(b + d) * self.B:(b + d + 1) * self.B] if b + d < nb else None
+            loss = self.pipelined_step(nxt, counter(b + d) if nxt is not None else None)
             total += loss
         return total / nb
 
@@ -438,6 +493,8 @@ class SageTrainEngine:
             raise RuntimeError("seed pool smaller than one batch")
         if self.primed:
             raise RuntimeError("a prefetched batch is pending")
+        if self.overlap_gather:
+            raise NotImplementedError("overlap_gather is an option of the eager pipeline")
         self.seed_pool = seed_pool.contiguous()
         self.split_gather = split_gather
         pool_len = (self.seed_pool.numel() // self.B) * self.B
@@ -454,10 +511,8 @@ class SageTrainEngine:
                 with torch.cuda.graph(gs[slot], stream=cap):
                     self.sample(self.seed_pool, counter0, slot=slot, ctrl=self.ctrl)
                     ops.ctrl_advance(self.ctrl, counter_stride, 1, self.B, pool_len)
-                    if self.overlap_gather and not split_gather:
-                        self.gather_layer0(slot)
                 with torch.cuda.graph(gc[slot], stream=cap):
-                    self.forward_backward(slot=slot, skip_gather0=split_gather or self.overlap_gather)
+                    self.forward_backward(slot=slot, skip_gather0=split_gather)
             # capture executes nothing: the host-side parity must end where it started, and the
             # first replay must read the word the eager steps wrote last
             par0 = self._adam_calls & 1
@@ -472,10 +527,7 @@ class SageTrainEngine:
         with torch.cuda.stream(self.side):
             self.side.wait_stream(torch.cuda.current_stream())
             gs[0].replay()
-            if self.overlap_gather and split_gather:
-                self.gather_layer0(0)
             self.ready[0].record(self.side)
-        self.primed = True
         self._first_replay = True
         return self
 
@@ -487,16 +539,10 @@ class SageTrainEngine:
             if not self._first_replay:
                 self.side.wait_event(self.consumed[1 - p])
             gs[1 - p].replay()
-            if self.overlap_gather and self.split_gather:
-                if before_gather is not None:
-                    before_gather()
-                self.gather_layer0(1 - p)
-                if after_gather is not None:
-                    after_gather()
             self.ready[1 - p].record(self.side)
         self._first_replay = False
         main.wait_event(self.ready[p])
-        if self.split_gather and not self.overlap_gather:
+        if self.split_gather:
             if before_gather is not None:
                 before_gather()
             self.gather_layer0(p)

@@ -43,9 +43,8 @@ def test_engine_matches_module_path(dev, aggregator):
     assert int(engine.step_dev) == 4
 
 
-@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("split", [False, True])
-def test_graph_replay_matches_eager_steps(dev, split, overlap):
+def test_graph_replay_matches_eager_steps(dev, split, overlap=False):
     """HIP-graph replay (device control block drives seeds / Philox counter / stamp) runs the
     same steps as eager engine.step, including the wrap at the end of the seed pool."""
     from graphsage_amd.datasets import planted_partition
@@ -102,16 +101,29 @@ def test_pipelined_eager_matches_serial_steps(dev, overlap):
                                              graph.labels(data), B, lr=1e-2, overlap_gather=ov)
     serial, piped = mk(model_a), mk(model_b, overlap)
     pool = torch.randperm(2000, generator=torch.Generator().manual_seed(1))[:6 * B].to(dev)
-    piped.prefetch(pool[:B], 0)
+    d = piped.depth
+    assert d == (2 if overlap else 1)
+    for s in range(d):
+        piped.prefetch(pool[s * B:(s + 1) * B], s)
+    with pytest.raises(RuntimeError):
+        piped.prefetch(pool[:B], 99)              # pipeline full
     for s in range(6):
         la = serial.step(pool[s * B:(s + 1) * B], counter=s).clone()
-        nxt = pool[(s + 1) * B:(s + 2) * B] if s < 5 else None
-        lb = piped.pipelined_step(nxt, s + 1).clone()
+        nxt = pool[(s + d) * B:(s + d + 1) * B] if s + d < 6 else None
+        lb = piped.pipelined_step(nxt, s + d).clone()
         n, e = int(serial.buf.state[0]), int(serial.buf.state[1])
         assert torch.equal(serial.buf.state, piped.buf.state)
         assert torch.equal(serial.buf.node[:n], piped.buf.node[:n])
         assert torch.equal(serial.buf.src[:e], piped.buf.src[:e])
         torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(piped.flat, serial.flat, rtol=1e-4, atol=1e-6)
+    assert not piped.primed
+    with pytest.raises(RuntimeError):
+        piped.pipelined_step()
+    # drained below its depth and refilled with ONE batch: still correct (gather on demand)
+    piped.prefetch(pool[:B], 50)
+    la = serial.step(pool[:B], counter=50).clone()
+    lb = piped.pipelined_step().clone()
+    torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
     assert torch.equal(serial.state_sum, piped.state_sum)
     piped.step(pool[:B], counter=99)          # pipeline drained: serial stepping works again
