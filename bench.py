@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
     ap.add_argument("--overlap-gather", action="store_true",
                     help="run the layer-0 gather of batch s+1 on the side stream during batch s")
+    ap.add_argument("--variant", default="fig2a", choices=["fig2a", "trainer"],
+                    help="fig2a: the benchmarked step (supervised term only, static-shape engine). "
+                         "trainer: the reference trainers' step (node_level_graphsage_trainers.py:34-46: "
+                         "+ unsupervised term = two more forwards on positive / negative nodes) on the "
+                         "module path; reported separately, never as the headline")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from HIP graphs instead of launching every kernel eagerly "
                          "(same arithmetic; measured 2-3 %% slower than eager on MI355X / ROCm 7.2)")
@@ -88,6 +93,53 @@ def cpu_baseline(data_cpu, colptr, row, seeds_list, fanout, layers, steps, lr):
     return len(seeds_list[0]) / per_step, cores, per_step, len(timed)
 
 
+def trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank):
+    """The reference trainers' step (3 forwards) through the module path (autograd Functions over
+    the same kernels): sample -> forward -> CE + unsupervised loss (positive = random in-neighbour,
+    negative = random node, both forwarded over the batch's edge_index) -> backward -> Adam."""
+    import torch.nn.functional as F
+
+    from graphsage_amd.samplers import UniformLoader, get_pos_neg_batches
+    if world != 1:
+        raise SystemExit("--variant trainer is a single-GPU measurement")
+    gen = torch.Generator().manual_seed(0)
+    train = torch.randperm(N, generator=gen)[:n_train]
+    loader = UniformLoader(data, num_neighbors=K, input_nodes=train, batch_size=B, shuffle=False, seed=0)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+
+    def step(batch):
+        opt.zero_grad()
+        y_hat = model.forward_batch(batch)
+        pos, neg = get_pos_neg_batches(batch, data)
+        pos_out = model(pos.x, pos.edge_index)[:batch.batch_size]
+        neg_out = model(neg.x, neg.edge_index)[:batch.batch_size]
+        unsup = -F.logsigmoid((y_hat * pos_out).sum(-1)).mean() - F.logsigmoid(-(y_hat * neg_out).sum(-1)).mean()
+        loss = F.cross_entropy(y_hat, batch.y[:batch.batch_size]) + unsup
+        loss.backward()
+        opt.step()
+        return loss
+
+    it = iter(loader)
+    for _ in range(args.warmup):
+        step(next(it))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(next(it))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "Reddit GraphSAGE-mean 25/10 fwd+bwd seed nodes/s; gather GB/s vs HBM peak",
+        "value": round(B * args.steps / elapsed, 1), "unit": "seed nodes/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}-shaped synthetic: N={N} E={E} F={Fdim} C={C}, B={B}/GPU, fan-out {K}, "
+                               f"hidden {args.hidden}, aggregator {args.aggregator}, Adam lr {args.lr}, TRAINER step "
+                               "(supervised + unsupervised term, 3 forwards, module path)",
+                   "parallelism": "dp1", "global_batch": B},
+        "roofline": None, "cpu_baseline": None, "final_loss": round(float(loss.detach()), 5), "variant": "trainer"}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -124,6 +176,8 @@ def main():
                    for m in model.layers]
     sampler = NeighborSampler.from_graph(graph, K, seed=0)   # the CSC is already resident
     pg = torch.distributed.group.WORLD if world > 1 else None
+    if args.variant == "trainer":
+        return trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank)
     engine = SageTrainEngine(model, sampler, feats, labels, B, lr=args.lr, world_size=world, process_group=pg,
                              overlap_gather=args.overlap_gather)
 
