@@ -235,6 +235,7 @@ def main():
     for s in range(args.warmup, args.warmup + args.steps):
         cur["i"] = s - args.warmup
         run_step(s, True)
+    engine.flush()                                 # data parallel: the last step's deferred Adam
     t_issued = time.perf_counter() - t0            # host-side enqueue time of the timed steps
     torch.cuda.synchronize()
     if world > 1:

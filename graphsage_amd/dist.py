@@ -20,8 +20,11 @@ def batch_counter(epoch, batches_per_epoch, batch, rank, world_size):
     return (epoch * batches_per_epoch + batch) * world_size + rank
 
 
-def all_reduce_flat(flat_grad, group=None):
-    """Sum the flat gradient buffer over ranks (the mean's 1/world is fused into Adam)."""
+def all_reduce_flat(flat_grad, group=None, async_op=False):
+    """Sum the flat gradient buffer over ranks (the mean's 1/world is fused into Adam).
+    async_op=True returns the work handle (None when there is nothing to reduce): the collective
+    runs on the backend's own stream and handle.wait() orders the current stream after it."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
-    return flat_grad
+        work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return work if async_op else flat_grad
+    return None if async_op else flat_grad

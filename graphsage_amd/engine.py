@@ -168,6 +168,7 @@ class SageTrainEngine:
         self.consumed = [torch.cuda.Event() for _ in range(self.nslots)]   # slot's compute finished
         self.started = torch.cuda.Event()    # main stream reached the start of a step
         self.queue = []         # slots sampled and not yet computed, oldest first
+        self._pending = None    # data parallel: (work handle) of a gradient all-reduce not yet applied
         self.gathered = [False] * self.nslots   # overlap_gather: slot's layer-0 aggregate is done
         self.used = [False] * self.nslots       # slot has been computed from at least once
         self.next_slot = 0
@@ -352,6 +353,7 @@ class SageTrainEngine:
         if counter is None:
             counter = self.counter
             self.counter += 1
+        self.flush()
         self.sample(seeds, counter, slot=0)
         self.forward_backward(slot=0)
         self.all_reduce()
@@ -423,12 +425,29 @@ class SageTrainEngine:
         self.queue.pop(0)
         if next_seeds is not None:
             self.prefetch(next_seeds, next_counter)
+        # data parallel: the previous step's all-reduce has been running on the collective's own
+        # stream while this step's sampler wait and (weight-free) layer-0 gather were enqueued;
+        # its Adam step goes here, just before the first kernel that reads the weights
+        self.flush()
         self.forward_backward(slot=p, skip_gather0=True)
-        self.all_reduce()
-        self.optimizer_step()
+        if self.world_size > 1:
+            self._pending = (all_reduce_flat(self.grad, self.pg, async_op=True),)
+        else:
+            self.optimizer_step()
         self.consumed[p].record(main)
         self.used[p] = True
         return self.loss
+
+    def flush(self):
+        """Apply a deferred optimizer step.  Under data parallelism pipelined_step() returns with
+        the gradient all-reduce in flight and applies Adam at the start of the next call (or
+        here): call flush() before reading the weights."""
+        if self._pending is not None:
+            work = self._pending[0]
+            self._pending = None
+            if work is not None:
+                work.wait()
+            self.optimizer_step()
 
     # ------------------------------------------------------------------ epochs and evaluation
     def train_epoch(self, seeds, epoch=0, rank=0):
@@ -452,6 +471,7 @@ class SageTrainEngine:
             nxt = seeds[(b + d) * self.B:(b + d + 1) * self.B] if b + d < nb else None
             loss = self.pipelined_step(nxt, counter(b + d) if nxt is not None else None)
             total += loss
+        self.flush()
         return total / nb
 
     @torch.no_grad()
@@ -462,6 +482,7 @@ class SageTrainEngine:
         Sampled fan-out neighbourhoods as in GraphSAGE.inference (models/graphsage.py:51-68)."""
         if self.primed:
             raise RuntimeError("a prefetched batch is pending")
+        self.flush()
         B = self.B
         n = seeds.numel()
         correct = torch.zeros(1, dtype=torch.int64, device=self.dev)
@@ -495,6 +516,7 @@ class SageTrainEngine:
             raise RuntimeError("a prefetched batch is pending")
         if self.overlap_gather:
             raise NotImplementedError("overlap_gather is an option of the eager pipeline")
+        self.flush()
         self.seed_pool = seed_pool.contiguous()
         self.split_gather = split_gather
         pool_len = (self.seed_pool.numel() // self.B) * self.B

@@ -49,6 +49,8 @@ def _worker(rank, world, port, out):
     for b in range(nb):
         nxt = mine[(b + 1) * B:(b + 2) * B] if b + 1 < nb else None
         losses.append(float(eng.pipelined_step(nxt, batch_counter(0, nb, b + 1, rank, world) if b + 1 < nb else None)))
+    assert int(eng.step_dev) == nb - 1        # the last Adam is deferred until flush()
+    eng.flush()
     torch.cuda.synchronize()
     out[rank] = (eng.flat.cpu(), losses, int(eng.step_dev))
     dist.destroy_process_group()
