@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--aggregator", default="mean")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--no-variant", action="store_true",
+                    help="skip the extra (untimed for `value`) measurement of the overlap_gather schedule")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
     ap.add_argument("--overlap-gather", action="store_true",
                     help="run the layer-0 gather of batch s+1 on the side stream during batch s")
@@ -277,6 +279,29 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
                         "algorithmic_bytes_per_launch": int(bytes_sum / args.steps), "row_stride_floats": int(ld)}
+        # Informational only (never `value`): the same step with overlap_gather — layer-0 gather of
+        # batch i+1 on the side stream beside the forward GEMM of batch i — measured right after
+        # the headline run on a second engine (DESIGN.md 4b says why it is not the default).
+        variant = None
+        if world == 1 and not args.overlap_gather and not use_graph and not args.no_variant:
+            import copy
+            model2 = copy.deepcopy(model)
+            eng2 = SageTrainEngine(model2, NeighborSampler.from_graph(graph, K, seed=0), feats, labels, B,
+                                   lr=args.lr, overlap_gather=True)
+            for d in range(eng2.depth):
+                eng2.prefetch(seeds_of(d), counter_of(d))
+            nv = min(args.steps, 200)
+            for s2 in range(args.warmup):
+                eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for s2 in range(args.warmup, args.warmup + nv):
+                eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
+            torch.cuda.synchronize()
+            tv = time.perf_counter() - tv
+            variant = {"schedule": "overlap_gather", "ms_per_step": round(tv / nv * 1e3, 4),
+                       "value": round(B * nv / tv, 1), "unit": "seed nodes/s", "steps": nv}
+            del eng2, model2
         cpu = None
         if world == 1 and args.cpu_steps > 0:
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
@@ -296,7 +321,7 @@ def main():
                                    f"B={B}/GPU, fan-out {K}, hidden {args.hidden}, aggregator {args.aggregator}, "
                                    f"Adam lr {args.lr}, fig2a step (supervised term only)",
                        "parallelism": f"dp{world}", "global_batch": world * B},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "variant_overlap_gather": variant,
             "final_loss": round(loss, 5), "setup_s": round(setup_s, 1),
             "avg_nodes_per_batch": float(st[ops.ST_NODES]) / args.steps,
             "avg_edges_per_batch": float(st[ops.ST_EDGES]) / args.steps,
