@@ -679,28 +679,39 @@ skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, SkinnyDwP
   if (m_beg >= m_end) return;
   const int col = blockIdx.x * kThreads + threadIdx.x;
   const int n0 = blockIdx.y * kDwRows;
-  int nidx[kDwRows];
-#pragma unroll
-  for (int i = 0; i < kDwRows; ++i) nidx[i] = n0 + i < n ? n0 + i : n - 1;
   float acc[kDwRows];
 #pragma unroll
   for (int i = 0; i < kDwRows; ++i) acc[i] = 0.f;
-  constexpr int U = 16;  // rows of m in flight (the slice is latency-bound: 2 round trips, not 8)
-  for (int64_t mm = m_beg; mm < m_end; mm += U) {
-    float av[U];
-    int64_t mc[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      mc[u] = mm + u < m_end ? mm + u : m_end - 1;
-      const int64_t r = rows != nullptr ? rows[mc[u]] : mc[u];
-      av[u] = (col < k && mm + u < m_end) ? a[r * ld_a + col] : 0.f;
+  // The block's kDwRows columns of dout are the same for every thread: stage 64 rows of them
+  // in LDS (one coalesced pass) and read them back as broadcasts, instead of 8 same-address
+  // global loads per row per thread.
+  constexpr int kStage = 64, U = 8;
+  __shared__ __attribute__((aligned(16))) float sd[kStage][kDwRows];
+  for (int64_t mm0 = m_beg; mm0 < m_end; mm0 += kStage) {
+    const int cnt = m_end - mm0 < kStage ? static_cast<int>(m_end - mm0) : kStage;
+    for (int q = threadIdx.x; q < kStage * kDwRows; q += kThreads) {
+      const int r = q / kDwRows, i = q % kDwRows;
+      sd[r][i] = (r < cnt && n0 + i < n) ? dout[(mm0 + r) * ld_dout + n0 + i] : 0.f;   // rows past cnt: 0
     }
+    __syncthreads();
+    for (int u0 = 0; u0 < cnt; u0 += U) {
+      float av[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float* drow = dout + mc[u] * ld_dout;
+      for (int u = 0; u < U; ++u) {
+        const int64_t mc = mm0 + u0 + u < m_end ? mm0 + u0 + u : m_end - 1;   // clamped: times 0 below
+        const int64_t r = rows != nullptr ? rows[mc] : mc;
+        av[u] = col < k ? a[r * ld_a + col] : 0.f;
+      }
 #pragma unroll
-      for (int i = 0; i < kDwRows; ++i) acc[i] += drow[nidx[i]] * av[u];
+      for (int u = 0; u < U; ++u) {
+        const float4 d0 = *reinterpret_cast<const float4*>(&sd[u0 + u < kStage ? u0 + u : kStage - 1][0]);
+        const float4 d1 = *reinterpret_cast<const float4*>(&sd[u0 + u < kStage ? u0 + u : kStage - 1][4]);
+        const float w = u0 + u < cnt ? av[u] : 0.f;
+        acc[0] += d0.x * w; acc[1] += d0.y * w; acc[2] += d0.z * w; acc[3] += d0.w * w;
+        acc[4] += d1.x * w; acc[5] += d1.y * w; acc[6] += d1.z * w; acc[7] += d1.w * w;
+      }
     }
+    __syncthreads();
   }
   if (col < k) {
 #pragma unroll
