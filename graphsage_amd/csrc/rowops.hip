@@ -16,6 +16,8 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr float kNormEps = 1e-12f;  // torch.nn.functional.normalize default
 
+inline bool vec16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -27,6 +29,9 @@ __device__ inline float wave_max(float v) {
   return v;
 }
 
+// V4: n and every row stride are multiples of 4 and the bases 16-byte aligned — each lane moves
+// 16-byte vectors (one per lane covers n = 256), twice the bytes per instruction of the scalar form
+template <bool V4>
 __global__ void __launch_bounds__(kBlock)
 l2norm_relu_fwd_kernel(const float* __restrict__ z, int64_t ld_z, int64_t m,
                        const int64_t* __restrict__ m_dev, int n, float* __restrict__ y,
@@ -38,20 +43,40 @@ l2norm_relu_fwd_kernel(const float* __restrict__ z, int64_t ld_z, int64_t m,
   if (r >= rows) return;
   const float* zr = z + r * ld_z;
   float ss = 0.f;
-  for (int f = lane; f < n; f += kWave) {
-    const float v = zr[f];
-    ss += v * v;
+  if constexpr (V4) {
+    for (int f = lane * 4; f < n; f += kWave * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(zr + f);
+      ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+  } else {
+    for (int f = lane; f < n; f += kWave) {
+      const float v = zr[f];
+      ss += v * v;
+    }
   }
   ss = wave_sum(ss);
   const float denom = fmaxf(sqrtf(ss), kNormEps);
   if (lane == 0 && inv_norm != nullptr) inv_norm[r] = 1.f / denom;
-  for (int f = lane; f < n; f += kWave) {
-    const float v = zr[f] / denom;
-    y[r * ld_y + f] = v;
-    if (h != nullptr) h[r * ld_h + f] = v > 0.f ? v : 0.f;
+  if constexpr (V4) {
+    for (int f = lane * 4; f < n; f += kWave * 4) {
+      float4 v = *reinterpret_cast<const float4*>(zr + f);
+      v.x /= denom; v.y /= denom; v.z /= denom; v.w /= denom;
+      *reinterpret_cast<float4*>(y + r * ld_y + f) = v;
+      if (h != nullptr) {
+        *reinterpret_cast<float4*>(h + r * ld_h + f) =
+            make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
+      }
+    }
+  } else {
+    for (int f = lane; f < n; f += kWave) {
+      const float v = zr[f] / denom;
+      y[r * ld_y + f] = v;
+      if (h != nullptr) h[r * ld_h + f] = v > 0.f ? v : 0.f;
+    }
   }
 }
 
+template <bool V4>
 __global__ void __launch_bounds__(kBlock)
 l2norm_relu_bwd_kernel(float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ y,
                        int64_t ld_y, const float* __restrict__ inv_norm, int relu_mask, int64_t m,
@@ -66,20 +91,51 @@ l2norm_relu_bwd_kernel(float* __restrict__ dh, int64_t ld_dh, const float* __res
   const float inv = inv_norm[r];
   const bool clamped = inv >= 1.f / kNormEps;  // ||z|| <= eps: the clamp's gradient is zero
   float dot = 0.f;
-  for (int f = lane; f < n; f += kWave) {
-    const float yv = yr[f];
-    float g = gr[f];
-    if (relu_mask && !(yv > 0.f)) g = 0.f;
-    dot += yv * g;
+  if constexpr (V4) {
+    for (int f = lane * 4; f < n; f += kWave * 4) {
+      const float4 yv = *reinterpret_cast<const float4*>(yr + f);
+      float4 g = *reinterpret_cast<const float4*>(gr + f);
+      if (relu_mask) {
+        if (!(yv.x > 0.f)) g.x = 0.f;
+        if (!(yv.y > 0.f)) g.y = 0.f;
+        if (!(yv.z > 0.f)) g.z = 0.f;
+        if (!(yv.w > 0.f)) g.w = 0.f;
+      }
+      dot += yv.x * g.x + yv.y * g.y + yv.z * g.z + yv.w * g.w;
+    }
+  } else {
+    for (int f = lane; f < n; f += kWave) {
+      const float yv = yr[f];
+      float g = gr[f];
+      if (relu_mask && !(yv > 0.f)) g = 0.f;
+      dot += yv * g;
+    }
   }
   dot = clamped ? 0.f : wave_sum(dot);
-  for (int f = lane; f < n; f += kWave) {
-    const float yv = yr[f];
-    float g = gr[f];
-    if (relu_mask && !(yv > 0.f)) g = 0.f;
-    dz[r * ld_dz + f] = (g - yv * dot) * inv;
-    // consume-and-clear: the next step's scatter-add starts from zeros without a fill kernel
-    if (clear_dh) gr[f] = 0.f;
+  if constexpr (V4) {
+    for (int f = lane * 4; f < n; f += kWave * 4) {
+      const float4 yv = *reinterpret_cast<const float4*>(yr + f);
+      float4 g = *reinterpret_cast<const float4*>(gr + f);
+      if (relu_mask) {
+        if (!(yv.x > 0.f)) g.x = 0.f;
+        if (!(yv.y > 0.f)) g.y = 0.f;
+        if (!(yv.z > 0.f)) g.z = 0.f;
+        if (!(yv.w > 0.f)) g.w = 0.f;
+      }
+      *reinterpret_cast<float4*>(dz + r * ld_dz + f) =
+          make_float4((g.x - yv.x * dot) * inv, (g.y - yv.y * dot) * inv, (g.z - yv.z * dot) * inv,
+                      (g.w - yv.w * dot) * inv);
+      // consume-and-clear: the next step's scatter-add starts from zeros without a fill kernel
+      if (clear_dh) *reinterpret_cast<float4*>(gr + f) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    for (int f = lane; f < n; f += kWave) {
+      const float yv = yr[f];
+      float g = gr[f];
+      if (relu_mask && !(yv > 0.f)) g = 0.f;
+      dz[r * ld_dz + f] = (g - yv * dot) * inv;
+      if (clear_dh) gr[f] = 0.f;
+    }
   }
 }
 
@@ -274,8 +330,15 @@ extern "C" int sage_l2norm_relu_fwd(const float* z, sage_i64 ld_z, sage_i64 m,
                SAGE_EINVAL, "sage_l2norm_relu_fwd: bad shape");
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(z && y, SAGE_EINVAL, "sage_l2norm_relu_fwd: NULL pointer argument");
-  l2norm_relu_fwd_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
-      z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm);
+  const bool v4 = n % 4 == 0 && ld_z % 4 == 0 && ld_y % 4 == 0 && (h == nullptr || ld_h % 4 == 0) &&
+                  vec16(z) && vec16(y) && vec16(h);
+  if (v4) {
+    l2norm_relu_fwd_kernel<true><<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+        z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm);
+  } else {
+    l2norm_relu_fwd_kernel<false><<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+        z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm);
+  }
   SAGE_CHECK_LAUNCH("l2norm_relu_fwd_kernel");
   return SAGE_OK;
 }
@@ -289,8 +352,15 @@ extern "C" int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, s
                "sage_l2norm_relu_bwd: bad shape");
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(dh && y && inv_norm && dz, SAGE_EINVAL, "sage_l2norm_relu_bwd: NULL pointer argument");
-  l2norm_relu_bwd_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
-      dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
+  const bool v4 = n % 4 == 0 && ld_dh % 4 == 0 && ld_y % 4 == 0 && ld_dz % 4 == 0 && vec16(dh) && vec16(y) &&
+                  vec16(dz);
+  if (v4) {
+    l2norm_relu_bwd_kernel<true><<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+        dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
+  } else {
+    l2norm_relu_bwd_kernel<false><<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+        dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
+  }
   SAGE_CHECK_LAUNCH("l2norm_relu_bwd_kernel");
   return SAGE_OK;
 }
