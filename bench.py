@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--aggregator", default="mean")
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--group", type=int, default=4,
+                    help="batches per cross-stream synchronisation of the eager pipeline (engine `group`)")
     ap.add_argument("--no-variant", action="store_true",
                     help="skip the extra (untimed for `value`) measurement of the overlap_gather schedule")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
@@ -181,7 +183,7 @@ def main():
     if args.variant == "trainer":
         return trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank)
     engine = SageTrainEngine(model, sampler, feats, labels, B, lr=args.lr, world_size=world, process_group=pg,
-                             overlap_gather=args.overlap_gather)
+                             overlap_gather=args.overlap_gather, group=args.group)
 
     # seeds: first n_train ids of randperm(N, seed 0); rank r takes the strided shard r::world
     gen = torch.Generator().manual_seed(0)

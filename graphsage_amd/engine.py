@@ -75,7 +75,7 @@ class SageTrainEngine:
 
     def __init__(self, model, sampler, features, labels, batch_size, lr=1e-3, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=0.0, world_size=1, process_group=None, overlap_gather=False,
-                 keep_grads=False):
+                 keep_grads=False, group=4):
         if model.aggregator not in _REDUCE:
             raise NotImplementedError(f"engine supports {sorted(_REDUCE)}, got {model.aggregator}")
         self.model = model
@@ -106,7 +106,13 @@ class SageTrainEngine:
         # sample-buffer slots: batch i computes from one while the sampler fills the next; with
         # overlap_gather a third one, because then the sampler runs TWO batches ahead
         self.overlap_gather = bool(overlap_gather)
-        self.nslots = 3 if self.overlap_gather else 2
+        # Cross-stream events are the expensive part of pipelining on this platform (a wait and
+        # a record on the main stream cost ~20 us per step, the sampler kernels beside the
+        # compute ~4): the main stream therefore synchronises with the sampler's stream once per
+        # GROUP of `group` batches — the sampler runs `group` batches ahead in a ring of
+        # 2*group slots.  overlap_gather needs a per-step hand-shake anyway: 3 slots, group 1.
+        self.group = 1 if self.overlap_gather else max(1, int(group))
+        self.nslots = 3 if self.overlap_gather else 2 * self.group
         self.bufs = [ops.SampleBuffers(self.graph.num_nodes, self.hop_cap[-1], edge_cap, dev)
                      for _ in range(self.nslots)]
         self.ctrl = torch.zeros(ops.CTRL_WORDS, dtype=torch.int64, device=dev)
@@ -162,27 +168,32 @@ class SageTrainEngine:
         self.counter = 0
         self.graphs = None
         self._tapes = {}        # recorded C-ABI call sequences, keyed by (what, slot, ..., stream)
+        self._pending = None    # data parallel: (work handle) of a gradient all-reduce not yet applied
         # pipelining state
         self.side = torch.cuda.Stream(device=dev)
-        self.ready = [torch.cuda.Event() for _ in range(self.nslots)]      # slot ready for compute
-        self.consumed = [torch.cuda.Event() for _ in range(self.nslots)]   # slot's compute finished
+        self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
+        self.cons_ev = [torch.cuda.Event(), torch.cuda.Event()]   # main stream finished a group
         self.started = torch.cuda.Event()    # main stream reached the start of a step
-        self.queue = []         # slots sampled and not yet computed, oldest first
-        self._pending = None    # data parallel: (work handle) of a gradient all-reduce not yet applied
+        self.n_pref = 0         # batches prefetched so far; batch n lives in slot n % nslots
+        self.n_comp = 0         # batches computed so far
+        self.main_ready_seq = -1   # newest batch whose sampling the main stream has waited for
+        self.cons_rec_seq = -1     # newest batch covered by a recorded cons_ev
+        self.side_cons_seq = -1    # newest batch whose compute the side stream has waited for
+        self.cons_latest = None
+        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]   # graph replay: slot's compute finished
+        self._main_touched = True   # the main stream used sample buffers outside the pipeline (step/evaluate)
         self.gathered = [False] * self.nslots   # overlap_gather: slot's layer-0 aggregate is done
-        self.used = [False] * self.nslots       # slot has been computed from at least once
-        self.next_slot = 0
         self.use = 0            # graph replay: slot the next compute reads
 
     @property
     def primed(self):
-        return bool(self.queue)
+        return self.n_pref > self.n_comp
 
     @property
     def depth(self):
         """How many batches ahead of the one being computed the sampler runs: callers prime the
         pipeline with `depth` prefetch() calls and hand pipelined_step() batch i + depth."""
-        return self.nslots - 1
+        return 2 if self.overlap_gather else self.group
 
     @property
     def step_dev(self):
@@ -354,6 +365,7 @@ class SageTrainEngine:
             counter = self.counter
             self.counter += 1
         self.flush()
+        self._main_touched = True
         self.sample(seeds, counter, slot=0)
         self.forward_backward(slot=0)
         self.all_reduce()
@@ -374,24 +386,30 @@ class SageTrainEngine:
         self.gathered[slot] = True
 
     def prefetch(self, seeds, counter, before_gather=None, after_gather=None):
-        """Sample `seeds` on the side stream into the next free slot.  Call it `depth` times
-        before the first pipelined_step()."""
-        if len(self.queue) >= self.depth:
+        """Sample `seeds` on the side stream into the next slot of the ring.  Call it `depth`
+        times before the first pipelined_step()."""
+        n = self.n_pref
+        if n - self.n_comp >= self.depth:
             raise RuntimeError("prefetch(): the pipeline is full")
-        slot = self.next_slot
-        self.next_slot = (slot + 1) % self.nslots
+        slot = n % self.nslots
         main = torch.cuda.current_stream()
-        if self.used[slot]:
-            self.side.wait_event(self.consumed[slot])
-        else:
+        need = n - self.nslots            # the batch that used this slot before
+        if n < self.nslots or need > self.cons_rec_seq or self._main_touched:
+            # first use of the slot, serial step()/evaluate() calls in between, or an irregular
+            # call sequence that no recorded event covers
             self.side.wait_stream(main)
+            self.side_cons_seq = self.n_comp - 1
+            self._main_touched = False
+        elif need > self.side_cons_seq:
+            self.side.wait_event(self.cons_latest)      # once per group in steady state
+            self.side_cons_seq = self.cons_rec_seq
         self.sample(seeds, counter, slot=slot, stream=self.side)
         seeds.record_stream(self.side)
         self.gathered[slot] = False
-        self.queue.append(slot)
+        self.n_pref = n + 1
         if not self.overlap_gather:
             self.ready[slot].record(self.side)
-        elif len(self.queue) == 1:
+        elif self.n_pref - self.n_comp == 1:
             # nothing is computing: no GEMM to hide behind, gather right away
             self._side_gather(slot, before_gather, after_gather)
             self.ready[slot].record(self.side)
@@ -400,29 +418,35 @@ class SageTrainEngine:
         """Train on the oldest prefetched batch while the side stream prepares the following ones:
         the sampler of batch i+depth and, with overlap_gather, the layer-0 gather of batch i+1
         (held back until this step has started, so that it runs beside the forward GEMM)."""
-        if not self.queue:
+        if self.n_pref == self.n_comp:
             raise RuntimeError("pipelined_step() needs a prefetch() first")
-        p = self.queue[0]
+        i = self.n_comp
+        p = i % self.nslots
         ov = self.overlap_gather
         main = torch.cuda.current_stream()
-        if ov and not self.gathered[p]:      # pipeline was drained below its depth
-            self._side_gather(p, None, None)
-            self.ready[p].record(self.side)
-        main.wait_event(self.ready[p])
         if ov:
-            if len(self.queue) > 1:
+            if not self.gathered[p]:      # pipeline was drained below its depth
+                self._side_gather(p, None, None)
+                self.ready[p].record(self.side)
+            main.wait_event(self.ready[p])
+            if self.n_pref - i > 1:
                 self.started.record(main)
                 self.side.wait_event(self.started)
-                q = self.queue[1]
+                q = (i + 1) % self.nslots
                 self._side_gather(q, before_gather, after_gather)
                 self.ready[q].record(self.side)
         else:
+            if i > self.main_ready_seq:
+                # one wait covers every batch prefetched so far (the side stream is in order)
+                newest = self.n_pref - 1
+                main.wait_event(self.ready[newest % self.nslots])
+                self.main_ready_seq = newest
             if before_gather is not None:
                 before_gather()
             self.gather_layer0(p)
             if after_gather is not None:
                 after_gather()
-        self.queue.pop(0)
+        self.n_comp = i + 1
         if next_seeds is not None:
             self.prefetch(next_seeds, next_counter)
         # data parallel: the previous step's all-reduce has been running on the collective's own
@@ -434,8 +458,10 @@ class SageTrainEngine:
             self._pending = (all_reduce_flat(self.grad, self.pg, async_op=True),)
         else:
             self.optimizer_step()
-        self.consumed[p].record(main)
-        self.used[p] = True
+        if (i + 1) % self.group == 0:
+            ev = self.cons_ev[(i // self.group) & 1]
+            ev.record(main)
+            self.cons_latest, self.cons_rec_seq = ev, i
         return self.loss
 
     def flush(self):
@@ -483,6 +509,7 @@ class SageTrainEngine:
         if self.primed:
             raise RuntimeError("a prefetched batch is pending")
         self.flush()
+        self._main_touched = True
         B = self.B
         n = seeds.numel()
         correct = torch.zeros(1, dtype=torch.int64, device=self.dev)

@@ -35,3 +35,14 @@ def piped():
     i[0] += 1
     eng.pipelined_step(seeds[(i[0] % 8) * 512:(i[0] % 8 + 1) * 512], 1000 + i[0])
 print(f"pipelined step (sampler on the side stream):          {timeit(piped):.1f} us")
+# --- sync cost alone: pipelined step with the sampler calls removed (both slots hold valid batches)
+while eng.queue:
+    eng.pipelined_step()
+torch.cuda.synchronize()
+real_sample = eng.sample
+eng.sample = lambda *a, **k: None
+eng.prefetch(seeds[:512], 1)
+print(f"pipelined, sampler kernels removed (events + waits only): {timeit(piped):.1f} us")
+while eng.queue:
+    eng.pipelined_step()
+eng.sample = real_sample

@@ -44,11 +44,13 @@ def _worker(rank, world, port, out):
     eng = _engine(data, model, dev, world_size=world, process_group=dist.group.WORLD)
     mine = shard_seeds(train, rank, world).to(dev)
     nb = mine.numel() // B
-    eng.prefetch(mine[:B], batch_counter(0, nb, 0, rank, world))
+    d = eng.depth
+    for b in range(min(d, nb)):
+        eng.prefetch(mine[b * B:(b + 1) * B], batch_counter(0, nb, b, rank, world))
     losses = []
     for b in range(nb):
-        nxt = mine[(b + 1) * B:(b + 2) * B] if b + 1 < nb else None
-        losses.append(float(eng.pipelined_step(nxt, batch_counter(0, nb, b + 1, rank, world) if b + 1 < nb else None)))
+        nxt = mine[(b + d) * B:(b + d + 1) * B] if b + d < nb else None
+        losses.append(float(eng.pipelined_step(nxt, batch_counter(0, nb, b + d, rank, world) if nxt is not None else None)))
     assert int(eng.step_dev) == nb - 1        # the last Adam is deferred until flush()
     eng.flush()
     torch.cuda.synchronize()
