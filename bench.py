@@ -51,11 +51,12 @@ def parse():
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
     ap.add_argument("--overlap-gather", action="store_true",
                     help="run the layer-0 gather of batch s+1 on the side stream during batch s")
-    ap.add_argument("--variant", default="fig2a", choices=["fig2a", "trainer"],
-                    help="fig2a: the benchmarked step (supervised term only, static-shape engine). "
-                         "trainer: the reference trainers' step (node_level_graphsage_trainers.py:34-46: "
-                         "+ unsupervised term = two more forwards on positive / negative nodes) on the "
-                         "module path; reported separately, never as the headline")
+    ap.add_argument("--variant", default="fig2a", choices=["fig2a", "trainer", "trainer-module"],
+                    help="fig2a: the benchmarked step (supervised term only). trainer: the reference "
+                         "trainers' step (node_level_graphsage_trainers.py:34-46: + unsupervised term = two "
+                         "more forwards on positive / negative nodes) on the static-shape engine; "
+                         "trainer-module: the same through the module path (autograd Functions).  Both "
+                         "are reported separately, never as the headline")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from HIP graphs instead of launching every kernel eagerly "
                          "(same arithmetic; measured 2-3 %% slower than eager on MI355X / ROCm 7.2)")
@@ -141,7 +142,7 @@ def trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, worl
                                f"hidden {args.hidden}, aggregator {args.aggregator}, Adam lr {args.lr}, TRAINER step "
                                "(supervised + unsupervised term, 3 forwards, module path)",
                    "parallelism": "dp1", "global_batch": B},
-        "roofline": None, "cpu_baseline": None, "final_loss": round(float(loss.detach()), 5), "variant": "trainer"}), flush=True)
+        "roofline": None, "cpu_baseline": None, "final_loss": round(float(loss.detach()), 5), "variant": "trainer-module"}), flush=True)
 
 
 def main():
@@ -180,10 +181,11 @@ def main():
                    for m in model.layers]
     sampler = NeighborSampler.from_graph(graph, K, seed=0)   # the CSC is already resident
     pg = torch.distributed.group.WORLD if world > 1 else None
-    if args.variant == "trainer":
+    if args.variant == "trainer-module":
         return trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank)
     engine = SageTrainEngine(model, sampler, feats, labels, B, lr=args.lr, world_size=world, process_group=pg,
-                             overlap_gather=args.overlap_gather, group=args.group)
+                             overlap_gather=args.overlap_gather, group=args.group,
+                             unsup=(args.variant == "trainer"))
 
     # seeds: first n_train ids of randperm(N, seed 0); rank r takes the strided shard r::world
     gen = torch.Generator().manual_seed(0)
@@ -285,7 +287,8 @@ def main():
         # batch i+1 on the side stream beside the forward GEMM of batch i — measured right after
         # the headline run on a second engine (DESIGN.md 4b says why it is not the default).
         variant = None
-        if world == 1 and not args.overlap_gather and not use_graph and not args.no_variant:
+        if world == 1 and not args.overlap_gather and not use_graph and not args.no_variant \
+                and args.variant == "fig2a":
             import copy
             model2 = copy.deepcopy(model)
             eng2 = SageTrainEngine(model2, NeighborSampler.from_graph(graph, K, seed=0), feats, labels, B,
@@ -321,13 +324,14 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic: N={N} E={E} F={Fdim} C={C}, "
                                    f"B={B}/GPU, fan-out {K}, hidden {args.hidden}, aggregator {args.aggregator}, "
-                                   f"Adam lr {args.lr}, fig2a step (supervised term only)",
+                                   f"Adam lr {args.lr}, " + ("fig2a step (supervised term only)" if args.variant == "fig2a" else
+                                                             "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},
             "roofline": roofline, "cpu_baseline": cpu, "variant_overlap_gather": variant,
             "final_loss": round(loss, 5), "setup_s": round(setup_s, 1),
             "avg_nodes_per_batch": float(st[ops.ST_NODES]) / args.steps,
             "avg_edges_per_batch": float(st[ops.ST_EDGES]) / args.steps,
-            "hip_graph": use_graph, "host_enqueue_ms_per_step": round(t_issued / args.steps * 1e3, 4), "overlap_gather": bool(args.overlap_gather),
+            "variant": args.variant, "hip_graph": use_graph, "host_enqueue_ms_per_step": round(t_issued / args.steps * 1e3, 4), "overlap_gather": bool(args.overlap_gather),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -27,7 +27,9 @@ SIGNATURES = {
                                         _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "sage_ctrl_advance": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P]),
     "sage_state_accumulate": (c_int, [_P, _P, _P]),
-    "sage_random_neighbor": (c_int, [_P, _P, _P, c_int64, c_uint64, c_uint64, _P, _P]),
+    "sage_random_nodes": (c_int, [c_int64, c_int64, c_uint64, c_uint64, _P, _P]),
+    "sage_unsup_loss": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P, _P, c_int64, _P, _P, _P]),
+    "sage_random_neighbor": (c_int, [_P, _P, c_int64, _P, c_int64, _P, c_uint64, c_uint64, _P, _P]),
     "sage_gather_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, c_int64, _P]),
     "sage_gather_reduce_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int,
                                        _P, c_int64, _P, _P]),

@@ -288,6 +288,41 @@ mean_reduce_kernel(const float* __restrict__ v, int64_t m, float* __restrict__ o
   if (threadIdx.x == 0) out[0] = partial[0] / static_cast<float>(m);
 }
 
+// Unsupervised GraphSAGE loss on row-normalised embeddings (reference trainers/base_trainers.py:
+// 179-181): loss = -mean logsigmoid(<out,pos>) - mean logsigmoid(-<out,neg>), and its gradient.
+// One wave per row.  d_out is ACCUMULATED (it already holds the supervised term's gradient).
+__device__ inline float log_sigmoid(float x) {   // stable: min(x,0) - log1p(exp(-|x|))
+  return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+__global__ void __launch_bounds__(kBlock)
+unsup_loss_kernel(const float* __restrict__ out, const float* __restrict__ pos,
+                  const float* __restrict__ neg, int64_t ld, int64_t m, int n, float grad_scale,
+                  float* __restrict__ d_out, float* __restrict__ d_pos, float* __restrict__ d_neg,
+                  int64_t ld_d, float* __restrict__ row_loss) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (r >= m) return;
+  float sp = 0.f, sn = 0.f;
+  for (int f = lane; f < n; f += kWave) {
+    const float o = out[r * ld + f];
+    sp += o * pos[r * ld + f];
+    sn += o * neg[r * ld + f];
+  }
+  sp = wave_sum(sp);
+  sn = wave_sum(sn);
+  if (lane == 0) row_loss[r] = -log_sigmoid(sp) - log_sigmoid(-sn);
+  // d/ds_p of -logsigmoid(s_p) = -sigmoid(-s_p);  d/ds_n of -logsigmoid(-s_n) = sigmoid(s_n)
+  const float scale = grad_scale / static_cast<float>(m);
+  const float gp = -scale / (1.f + expf(sp));
+  const float gn = scale / (1.f + expf(-sn));
+  for (int f = lane; f < n; f += kWave) {
+    const float o = out[r * ld + f], pv = pos[r * ld + f], nv = neg[r * ld + f];
+    d_out[r * ld_d + f] += gp * pv + gn * nv;
+    d_pos[r * ld_d + f] = gp * o;
+    d_neg[r * ld_d + f] = gn * o;
+  }
+}
+
 __global__ void adam_kernel(float* __restrict__ param, const float* grad,
                             float* __restrict__ exp_avg, float* __restrict__ exp_avg_sq,
                             int64_t numel, float lr, float beta1, float beta2, float eps,
@@ -415,6 +450,22 @@ extern "C" int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* l
   logits_xent_fused_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
       z, ld_z, labels, label_rows, m, n, grad_scale, y, ld_y, inv_norm, dz, ld_dz, row_loss, clear_z);
   SAGE_CHECK_LAUNCH("logits_xent_fused_kernel");
+  mean_reduce_kernel<<<1, kBlock, 0, stream>>>(row_loss, m, loss);
+  SAGE_CHECK_LAUNCH("mean_reduce_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_unsup_loss(const float* out, const float* pos, const float* neg, sage_i64 ld,
+                               sage_i64 m, int n, float grad_scale, float* d_out, float* d_pos,
+                               float* d_neg, sage_i64 ld_d, float* row_loss, float* loss,
+                               void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m > 0 && n > 0 && ld >= n && ld_d >= n, SAGE_EINVAL, "sage_unsup_loss: bad shape");
+  SAGE_REQUIRE(out && pos && neg && d_out && d_pos && d_neg && row_loss && loss, SAGE_EINVAL,
+               "sage_unsup_loss: NULL pointer argument");
+  unsup_loss_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+      out, pos, neg, ld, m, n, grad_scale, d_out, d_pos, d_neg, ld_d, row_loss);
+  SAGE_CHECK_LAUNCH("unsup_loss_kernel");
   mean_reduce_kernel<<<1, kBlock, 0, stream>>>(row_loss, m, loss);
   SAGE_CHECK_LAUNCH("mean_reduce_kernel");
   return SAGE_OK;

@@ -275,14 +275,30 @@ __global__ void tail_kernel(const int64_t* __restrict__ state, int64_t node_cap,
   if (t >= state[SAGE_ST_FRONT_BEGIN]) seg_ptr[t] = state[SAGE_ST_EDGES];
 }
 
+// negative samples: one uniform node id per slot (reference samplers/utils.py:30-31, torch.randint)
+__global__ void random_nodes_kernel(int64_t num_nodes, int64_t n, uint32_t seed_lo, uint32_t seed_hi,
+                                    uint32_t ctr_lo, uint32_t ctr_hi, int64_t* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // counter word 1 is a domain tag ("NE") that separates this stream from the others
+  Philox4 p = philox4x32_10(static_cast<uint32_t>(i >> 2), 0x4E450000u + static_cast<uint32_t>(i >> 34),
+                            ctr_lo, ctr_hi, seed_lo, seed_hi);
+  out[i] = mulhi_range(philox_word(p, static_cast<int>(i & 3)), static_cast<uint32_t>(num_nodes));
+}
+
 __global__ void random_neighbor_kernel(const int64_t* __restrict__ colptr,
-                                       const int64_t* __restrict__ row,
+                                       const int64_t* __restrict__ row, int64_t num_nodes,
                                        const int64_t* __restrict__ start, int64_t n,
+                                       const int64_t* __restrict__ n_dev,
                                        uint32_t seed_lo, uint32_t seed_hi, uint32_t ctr_lo,
                                        uint32_t ctr_hi, int64_t* __restrict__ out) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= dev_count(n_dev, n)) return;
   const int64_t s = start[i];
+  if (s < 0 || s >= num_nodes) {   // never index colptr with an id that is not a node
+    out[i] = 0;
+    return;
+  }
   const int64_t cs = colptr[s];
   const int64_t deg = colptr[s + 1] - cs;
   if (deg == 0) {
@@ -463,18 +479,33 @@ extern "C" int sage_ctrl_advance(sage_i64* ctrl_dev, sage_i64 d_counter, sage_i6
   return SAGE_OK;
 }
 
-extern "C" int sage_random_neighbor(const sage_i64* colptr, const sage_i64* row,
-                                    const sage_i64* start, sage_i64 num_start, uint64_t rng_seed,
+extern "C" int sage_random_neighbor(const sage_i64* colptr, const sage_i64* row, sage_i64 num_nodes,
+                                    const sage_i64* start, sage_i64 num_start,
+                                    const sage_i64* num_start_dev, uint64_t rng_seed,
                                     uint64_t rng_counter, sage_i64* out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(colptr && row && out && (start || num_start == 0), SAGE_EINVAL,
                "sage_random_neighbor: NULL pointer argument");
+  SAGE_REQUIRE(num_nodes > 0, SAGE_EINVAL, "sage_random_neighbor: bad num_nodes");
   if (num_start <= 0) return SAGE_OK;
   random_neighbor_kernel<<<static_cast<int>(cdiv(num_start, kBlock)), kBlock, 0, stream>>>(
-      colptr, row, start, num_start, static_cast<uint32_t>(rng_seed),
+      colptr, row, num_nodes, start, num_start, num_start_dev, static_cast<uint32_t>(rng_seed),
       static_cast<uint32_t>(rng_seed >> 32), static_cast<uint32_t>(rng_counter),
       static_cast<uint32_t>(rng_counter >> 32), out);
   SAGE_CHECK_LAUNCH("random_neighbor_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_random_nodes(sage_i64 num_nodes, sage_i64 n, uint64_t rng_seed, uint64_t rng_counter,
+                                 sage_i64* out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(num_nodes > 0 && num_nodes < (1ll << 31), SAGE_EINVAL, "sage_random_nodes: bad num_nodes");
+  SAGE_REQUIRE(out != nullptr || n == 0, SAGE_EINVAL, "sage_random_nodes: NULL pointer argument");
+  if (n <= 0) return SAGE_OK;
+  random_nodes_kernel<<<static_cast<int>(cdiv(n, kBlock)), kBlock, 0, stream>>>(
+      num_nodes, n, static_cast<uint32_t>(rng_seed), static_cast<uint32_t>(rng_seed >> 32),
+      static_cast<uint32_t>(rng_counter), static_cast<uint32_t>(rng_counter >> 32), out);
+  SAGE_CHECK_LAUNCH("random_nodes_kernel");
   return SAGE_OK;
 }
 

@@ -75,7 +75,7 @@ class SageTrainEngine:
 
     def __init__(self, model, sampler, features, labels, batch_size, lr=1e-3, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=0.0, world_size=1, process_group=None, overlap_gather=False,
-                 keep_grads=False, group=4):
+                 keep_grads=False, group=4, unsup=False):
         if model.aggregator not in _REDUCE:
             raise NotImplementedError(f"engine supports {sorted(_REDUCE)}, got {model.aggregator}")
         self.model = model
@@ -138,21 +138,40 @@ class SageTrainEngine:
             ld = (cols + 15) // 16 * 16
             return torch.zeros((rows, ld), dtype=torch.float32, device=dev)[:, :cols]
 
-        self.act = []   # per layer: dict of static buffers
-        for i, layer in enumerate(model.layers):
-            t_cap = self.hop_cap[self.L - 1 - i]
-            fin = layer.lin_l.weight.size(1)
-            fout = layer.lin_l.weight.size(0)
-            a = dict(t_cap=t_cap, fin=fin, fout=fout, hop=self.L - 1 - i,
-                     agg=padded(t_cap, fin), z=padded(t_cap, fout), y=padded(t_cap, fout),
-                     inv=torch.zeros(t_cap, dtype=torch.float32, device=dev),
-                     dz=padded(t_cap, fout))
-            if i < self.L - 1:
-                a['h'] = padded(t_cap, fout)
-                a['dh'] = padded(t_cap, fout)
-            if i > 0:
-                a['dagg'] = padded(t_cap, fin)
-            self.act.append(a)
+        # unsup: the reference trainers' step (trainers/node_level_graphsage_trainers.py:41) adds
+        # the unsupervised term — two more forwards over the SAME sampled edges with the features of
+        # positive / negative nodes in place of the batch's (trainers/base_trainers.py:170-181) —
+        # so every activation exists three times (variant 0 = batch, 1 = positive, 2 = negative)
+        self.unsup = bool(unsup)
+        nvar = 3 if self.unsup else 1
+
+        def make_act():
+            act = []
+            for i, layer in enumerate(model.layers):
+                t_cap = self.hop_cap[self.L - 1 - i]
+                fin = layer.lin_l.weight.size(1)
+                fout = layer.lin_l.weight.size(0)
+                a = dict(t_cap=t_cap, fin=fin, fout=fout, hop=self.L - 1 - i,
+                         agg=padded(t_cap, fin), z=padded(t_cap, fout), y=padded(t_cap, fout),
+                         inv=torch.zeros(t_cap, dtype=torch.float32, device=dev),
+                         dz=padded(t_cap, fout))
+                if i < self.L - 1:
+                    a['h'] = padded(t_cap, fout)
+                    a['dh'] = padded(t_cap, fout)
+                else:
+                    a['dy'] = padded(t_cap, fout)     # unsup: gradient w.r.t. the normalised logits
+                if i > 0:
+                    a['dagg'] = padded(t_cap, fin)
+                act.append(a)
+            return act
+        self.acts = [make_act() for _ in range(nvar)]
+        self.act = self.acts[0]   # per layer: dict of static buffers (variant 0)
+        if self.unsup:
+            self.pos_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
+            self.neg_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
+            self.loss_sup = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.loss_unsup = torch.zeros(1, dtype=torch.float32, device=dev)
+            self.slot_counter = [0] * self.nslots
         # layer-0 aggregate per sample slot: with overlap_gather the HBM-bound gather of batch i+1
         # runs on the side stream (it needs no weights) beside the MFMA-bound forward GEMM of
         # batch i, into a buffer of its own
@@ -215,6 +234,8 @@ class SageTrainEngine:
             ops.state_accumulate(self.bufs[slot].state, self.state_sum)
             return
         self._stamp += 1
+        if self.unsup:
+            self.slot_counter[slot] = counter
         handle = (stream or torch.cuda.current_stream()).cuda_stream
         key = ('sample', slot, handle)
         entry = self._tapes.get(key)
@@ -273,6 +294,8 @@ class SageTrainEngine:
 
     def forward_backward(self, slot=0, skip_gather0=False):
         self.last_slot = slot
+        if self.unsup:
+            self.make_pos_neg(slot, self.slot_counter[slot])
 
         def both():
             self._forward(slot, skip_gather0)
@@ -283,61 +306,111 @@ class SageTrainEngine:
         """Layers + normalised logits + per-row cross entropy (and dz of the last layer, which
         the fused kernel produces in the same pass)."""
         self.last_slot = slot
+        if self.unsup:
+            self.make_pos_neg(slot, self.slot_counter[slot])
         self._taped('f%d' % skip_gather0, slot, lambda: self._forward(slot, skip_gather0))
 
     def backward(self, slot=0):
         self._taped('b', slot, lambda: self._backward(slot))
 
-    def _forward(self, slot, skip_gather0):
+    def _node_map(self, slot, v):
+        return (self.bufs[slot].node, self.pos_id, self.neg_id)[v] if self.unsup else self.bufs[slot].node
+
+    def _agg0(self, slot, v):
+        return self.agg0[slot] if v == 0 else self.acts[v][0]['agg']
+
+    def _forward_layers(self, slot, v, skip_gather0):
+        """Layers of variant v up to the un-normalised logits z."""
         L, buf = self.L, self.bufs[slot]
-        x, node_map = self.features, buf.node
+        act = self.acts[v]
+        x, node_map = self.features, self._node_map(slot, v)
         lib = ops
         for i, layer in enumerate(self.model.layers):
-            a = self.act[i]
+            a = act[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
-            agg = self.agg0[slot] if i == 0 else a['agg']
+            agg = self._agg0(slot, v) if i == 0 else a['agg']
             if i == 0:
-                if not skip_gather0:
+                if v > 0:
+                    lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=node_map,
+                                          num_targets_dev=t_dev, out=agg, want_argmax=False)
+                elif not skip_gather0:
                     self._gather_layer0(slot)
             else:
                 lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
                                       num_targets_dev=t_dev, out=agg, want_argmax=False)
-            # the logit layer accumulates its split-K partial sums into z, which the fused loss
-            # kernel below hands back zeroed (z starts as zeros): no fill kernel
+            # supervised step: the logit layer accumulates its split-K partial sums into z, which
+            # the fused loss kernel hands back zeroed (z starts as zeros): no fill kernel
             lib.linear_concat_fwd(agg, layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
-                                  m_dev=t_dev, rows2=node_map, out=a['z'], accumulate=(i == L - 1))
+                                  m_dev=t_dev, rows2=node_map, out=a['z'],
+                                  accumulate=(i == L - 1 and not self.unsup))
             if i < L - 1:
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'])
             x, node_map = a.get('h'), None
-        # last layer: normalise + cross-entropy on the seed rows + gradient w.r.t. z, one kernel
-        last = self.act[-1]
-        lib.logits_xent_fused(last['z'], self.labels, buf.node, self.B, last['y'], last['inv'], last['dz'],
-                              self.row_loss, self.loss, clear_z=True)
+
+    def _forward(self, slot, skip_gather0):
+        buf, lib, B = self.bufs[slot], ops, self.B
+        if not self.unsup:
+            self._forward_layers(slot, 0, skip_gather0)
+            # last layer: normalise + cross-entropy on the seed rows + gradient w.r.t. z, one kernel
+            last = self.act[-1]
+            lib.logits_xent_fused(last['z'], self.labels, buf.node, B, last['y'], last['inv'], last['dz'],
+                                  self.row_loss, self.loss, clear_z=True)
+            return
+        for v in range(3):
+            self._forward_layers(slot, v, skip_gather0)
+            last = self.acts[v][-1]
+            lib.l2norm_relu_fwd(last['z'], False, m=B, y=last['y'], inv_norm=last['inv'])
+        l0, l1, l2 = (self.acts[v][-1] for v in range(3))
+        # loss = CE(out, y) + unsup(out, pos_out, neg_out)   (node_level_graphsage_trainers.py:41)
+        lib.softmax_xent(l0['y'], self.labels, label_rows=buf.node, m=B, loss=self.loss_sup, dlogits=l0['dy'],
+                         checked=True)
+        lib.unsup_loss(l0['y'], l1['y'], l2['y'], l0['dy'], l1['dy'], l2['dy'], self.row_loss, self.loss_unsup, m=B)
+        _lib.tape_py(lambda: torch.add(self.loss_sup, self.loss_unsup, out=self.loss))
+        for v in range(3):
+            last = self.acts[v][-1]
+            lib.l2norm_relu_bwd(last['dy'], last['y'], last['inv'], False, m=B, dz=last['dz'])
 
     def _backward(self, slot):
-        L, buf = self.L, self.bufs[slot]
-        lib = ops
         if self.keep_grads:
             _lib.tape_py(self.grad.zero_)
+        for v in range(3 if self.unsup else 1):
+            self._backward_layers(slot, v)
+
+    def _backward_layers(self, slot, v):
+        L, buf = self.L, self.bufs[slot]
+        act = self.acts[v]
+        lib = ops
         # (the upper layers' weight gradients are leaves of the dependency chain, but forking
         # them onto another stream costs more in cross-queue waits than the ~20 us it hides:
         # measured 0.41 -> 0.45 ms/step on MI355X / ROCm 7.2, so everything stays on one stream)
         for i in range(L - 1, -1, -1):
-            a, layer = self.act[i], self.model.layers[i]
+            a, layer = act[i], self.model.layers[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
             if i < L - 1:   # g = gradient w.r.t. relu(normalize(z)), left in dh by layer i+1
                 lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'],
                                     clear_dh=True)   # dh is zero again for the next step's scatter-add
-            x_in = self.features if i == 0 else self.act[i - 1]['h']
-            rows = buf.node if i == 0 else None
-            lib.linear_dweight2(a['dz'], self.agg0[slot] if i == 0 else a['agg'], self.gviews[layer.lin_l.weight],
-                                x_in, self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
+            x_in = self.features if i == 0 else act[i - 1]['h']
+            rows = self._node_map(slot, v) if i == 0 else None
+            lib.linear_dweight2(a['dz'], self._agg0(slot, v) if i == 0 else a['agg'],
+                                self.gviews[layer.lin_l.weight], x_in, self.gviews[layer.lin_r.weight],
+                                m=t_cap, m_dev=t_dev, rows2=rows)
             if i > 0:
-                prev = self.act[i - 1]
+                prev = act[i - 1]
                 lib.linear_dinput2(a['dz'], layer.lin_r.weight, prev['dh'], layer.lin_l.weight, a['dagg'],
                                    m=t_cap, m_dev=t_dev)
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       num_targets_dev=t_dev)
+
+    def make_pos_neg(self, slot, counter):
+        """unsup: positive = one uniform in-neighbour of every batch node in the full graph,
+        negative = a uniform node (graphsage_amd/samplers/utils.py; reference samplers/utils.py:7-37).
+        Only the batch's nodes (device-side count) are walked; later entries of pos_id keep older
+        valid ids and are never read through a segment."""
+        buf = self.bufs[slot]
+        ops.random_neighbor(self.graph.colptr, self.graph.row, buf.node, self.rng_seed, counter,
+                            out=self.pos_id, checked=False,
+                            num_dev=buf.state[ops.ST_NODES:ops.ST_NODES + 1])
+        ops.random_nodes(self.graph.num_nodes, self.pos_id.numel(), self.rng_seed, counter, out=self.neg_id)
 
     def all_reduce(self):
         if self.world_size > 1:
@@ -541,8 +614,8 @@ class SageTrainEngine:
             raise RuntimeError("seed pool smaller than one batch")
         if self.primed:
             raise RuntimeError("a prefetched batch is pending")
-        if self.overlap_gather:
-            raise NotImplementedError("overlap_gather is an option of the eager pipeline")
+        if self.overlap_gather or self.unsup:
+            raise NotImplementedError("overlap_gather / unsup are options of the eager pipeline")
         self.flush()
         self.seed_pool = seed_pool.contiguous()
         self.split_gather = split_gather

@@ -173,20 +173,65 @@ def ctrl_advance(ctrl, d_counter, d_stamp, d_offset, offset_wrap):
     _lib.check(rc, "sage_ctrl_advance")
 
 
-def random_neighbor(colptr, row, start, rng_seed, rng_counter):
-    """torch_cluster.random_walk(..., walk_length=1)[:, 1] (reference samplers/utils.py:22)."""
+def random_neighbor(colptr, row, start, rng_seed, rng_counter, out=None, checked=True, num_dev=None):
+    """torch_cluster.random_walk(..., walk_length=1)[:, 1] (reference samplers/utils.py:22).
+    checked=False skips the host-side range check of `start` (it synchronises; the kernel itself
+    never dereferences an id outside the graph).  num_dev: optional device-side count limiting
+    how many entries of `start` are processed (the sampler's node count)."""
     lib = _lib.load()
     start = start.contiguous()
-    out = torch.empty_like(start)
-    if start.numel() and (int(start.min()) < 0 or int(start.max()) >= colptr.numel() - 1):
+    if out is None:
+        out = torch.empty_like(start)
+    elif out.numel() < start.numel() or not out.is_contiguous():
+        raise RuntimeError("random_neighbor: bad output buffer")
+    if checked and start.numel() and (int(start.min()) < 0 or int(start.max()) >= colptr.numel() - 1):
         raise RuntimeError("random_neighbor: start node out of range")
     rc = lib.sage_random_neighbor(_vec(colptr, torch.int64, "colptr"), _vec(row, torch.int64, "row"),
-                                  _vec(start, torch.int64, "start"), start.numel(),
+                                  colptr.numel() - 1, _vec(start, torch.int64, "start"), start.numel(),
+                                  _count(num_dev, "num_dev"),
                                   int(rng_seed) & 0xFFFFFFFFFFFFFFFF,
                                   int(rng_counter) & 0xFFFFFFFFFFFFFFFF,
                                   _p(out, torch.int64, "out"), _stream())
     _lib.check(rc, "sage_random_neighbor")
     return out
+
+
+def random_nodes(num_nodes, n, rng_seed, rng_counter, device=None, out=None):
+    """torch.randint(0, num_nodes, (n,)) on a Philox counter stream (reference
+    samplers/utils.py:30-31: the negative samples)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(n, dtype=torch.int64, device=device)
+    elif out.numel() < n or not out.is_contiguous():
+        raise RuntimeError("random_nodes: bad output buffer")
+    rc = lib.sage_random_nodes(int(num_nodes), int(n), int(rng_seed) & 0xFFFFFFFFFFFFFFFF,
+                               int(rng_counter) & 0xFFFFFFFFFFFFFFFF, _p(out, torch.int64, "out"), _stream())
+    _lib.check(rc, "sage_random_nodes")
+    return out
+
+
+def unsup_loss(out, pos, neg, d_out, d_pos, d_neg, row_loss, loss, m=None, grad_scale=1.0):
+    """Unsupervised loss (reference trainers/base_trainers.py:179-181) + gradients; d_out is
+    accumulated, d_pos / d_neg overwritten.  All [m, n] fp32 with one common row stride per group."""
+    lib = _lib.load()
+    op, ld = _mat(out, "out")
+    pp, ld_p = _mat(pos, "pos")
+    np_, ld_n = _mat(neg, "neg")
+    dop, ld_d = _mat(d_out, "d_out")
+    dpp, ld_dp = _mat(d_pos, "d_pos")
+    dnp, ld_dn = _mat(d_neg, "d_neg")
+    m = out.size(0) if m is None else int(m)
+    n = out.size(1)
+    if ld_p != ld or ld_n != ld or ld_dp != ld_d or ld_dn != ld_d:
+        raise RuntimeError("unsup_loss: out/pos/neg (and the three gradients) must share a row stride")
+    for t in (out, pos, neg, d_out, d_pos, d_neg):
+        if t.size(0) < m or t.size(1) != n:
+            raise RuntimeError("unsup_loss: shape mismatch")
+    if row_loss.numel() < m or m <= 0:
+        raise RuntimeError("unsup_loss: bad row_loss / m")
+    rc = lib.sage_unsup_loss(op, pp, np_, ld, m, n, float(grad_scale), dop, dpp, dnp, ld_d,
+                             _vec(row_loss, torch.float32, "row_loss"), _p(loss, torch.float32, "loss"), _stream())
+    _lib.check(rc, "sage_unsup_loss")
 
 
 # ------------------------------------------------------------------------------- a-3

@@ -7,7 +7,8 @@ epoch instead of loss.item() per step, :46); micro-F1 is computed on the device 
 single-label predictions f1_score(average='micro') equals accuracy, which is what :56-57 compute
 twice.  With `supervised_only=True` (fig2a's step definition, experiments/fig2a/runners/
 graphsage_runners.py:38-46) and a mean/sum model trained with cross entropy + Adam, the epoch runs
-on the static-shape engine (graphsage_amd/engine.py).
+on the static-shape engine (graphsage_amd/engine.py); `use_engine=True` also puts the full step
+(supervised + unsupervised term, three forwards) on the engine.
 
 The unsupervised trainer's downstream classifier is sklearn's SGDClassifier in the reference
 (:122-125); sklearn baselines are out of scope (§8), so test() here fits a logistic-regression
@@ -44,8 +45,6 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
 
     def _make_engine(self):
         from ..engine import SageTrainEngine
-        if not self.supervised_only:
-            raise RuntimeError("the engine runs the supervised term only (supervised_only=True)")
         if not isinstance(self.optimizer, torch.optim.Adam):
             raise RuntimeError("the engine implements Adam")
         g = self.optimizer.param_groups[0]
@@ -53,7 +52,7 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
         graph = sampler.graph
         return SageTrainEngine(self.model, sampler, graph.features(self.data), graph.labels(self.data),
                                self.train_loader.batch_size, lr=g['lr'], betas=g['betas'], eps=g['eps'],
-                               weight_decay=g['weight_decay'])
+                               weight_decay=g['weight_decay'], unsup=not self.supervised_only)
 
     def train(self, epoch):
         self.model.train()

@@ -143,6 +143,12 @@ int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* row, sage_i6
 int sage_ctrl_advance(sage_i64* ctrl_dev, sage_i64 d_counter, sage_i64 d_stamp, sage_i64 d_offset,
                       sage_i64 offset_wrap, void* stream);
 
+/* (f-2) one uniform random node id per slot: the negative samples of
+ * samplers/utils.py:30-31 (torch.randint(0, num_nodes, (n,))).  Philox key = rng_seed,
+ * counter = (i>>2, 0x4E450000, rng_counter lo, hi), range reduction mulhi32(u, num_nodes). */
+int sage_random_nodes(sage_i64 num_nodes, sage_i64 n, uint64_t rng_seed, uint64_t rng_counter,
+                      sage_i64* out, void* stream);
+
 /* sum[0:SAGE_STATE_WORDS] += state[...]: running totals of the batch sizes the sampler
  * reported (the device-side counterpart of `total_examples += batch.batch_size`,
  * experiments/fig2a/runners/graphsage_runners.py:48, without reading the sizes back). */
@@ -150,11 +156,13 @@ int sage_state_accumulate(const sage_i64* state, sage_i64* sum, void* stream);
 
 /* (f-2) one uniform random in-neighbour per start node; replaces
  * torch_cluster.random_walk(row, col, start, walk_length=1)[:,1] at samplers/utils.py:22.
- * A start with no neighbour returns itself (torch_cluster's behaviour).  Philox key =
+ * A start with no neighbour returns itself (torch_cluster's behaviour); a start id outside
+ * [0, num_nodes) yields 0 and touches no memory.  Philox key =
  * (rng_seed), counter = (i>>2, 0x52570000, rng_counter lo, hi). */
-int sage_random_neighbor(const sage_i64* colptr, const sage_i64* row, const sage_i64* start,
-                         sage_i64 num_start, uint64_t rng_seed, uint64_t rng_counter,
-                         sage_i64* out, void* stream);
+int sage_random_neighbor(const sage_i64* colptr, const sage_i64* row, sage_i64 num_nodes,
+                         const sage_i64* start, sage_i64 num_start,
+                         const sage_i64* num_start_dev /* optional device-side count, limits num_start */,
+                         uint64_t rng_seed, uint64_t rng_counter, sage_i64* out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-3) Row gather.  Replaces torch_geometric.loader.utils.filter_data's
@@ -312,6 +320,15 @@ int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* labels,
                            float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
                            float* row_loss /*[m]*/, float* loss /*[1]*/,
                            int clear_z /* 1: z rows are zeroed after use */, void* stream);
+
+/* (f-2) unsupervised loss of trainers/base_trainers.py:179-181 on m rows of width n:
+ *   loss[0] = -mean logsigmoid(<out_i, pos_i>) - mean logsigmoid(-<out_i, neg_i>)
+ * and its gradient times grad_scale: d_out is ACCUMULATED (it may already hold the supervised
+ * term's gradient, node_level_graphsage_trainers.py:41), d_pos / d_neg are overwritten.
+ * row_loss[m] is scratch for the deterministic mean. */
+int sage_unsup_loss(const float* out, const float* pos, const float* neg, sage_i64 ld, sage_i64 m,
+                    int n, float grad_scale, float* d_out, float* d_pos, float* d_neg,
+                    sage_i64 ld_d, float* row_loss, float* loss, void* stream);
 
 /* Adam (torch.optim.Adam defaults semantics, no amsgrad, L2 weight_decay added to the
  * gradient) on one flat parameter buffer (optimizer.step() of

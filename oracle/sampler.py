@@ -114,3 +114,16 @@ def random_neighbor(colptr, row, start, rng_seed=0, rng_counter=0):
     pick = mulhi_range(u[has], deg[has].astype(np.uint64))
     out[has] = row[cs[has] + pick]
     return out
+
+
+def random_nodes(num_nodes, n, rng_seed=0, rng_counter=0):
+    """torch.randint(0, num_nodes, (n,)) restated on the build's Philox stream (reference
+    samplers/utils.py:30-31, negative samples): counter (i>>2, 0x4E450000 + (i>>34),
+    rng_counter), key rng_seed, word i&3, range reduction mulhi32(u, num_nodes)."""
+    i = np.arange(n, dtype=np.int64)
+    words = philox4x32_10((i >> 2).astype(np.uint32), (np.int64(0x4E450000) + (i >> 34)).astype(np.uint32),
+                          np.uint32(rng_counter & 0xFFFFFFFF), np.uint32((rng_counter >> 32) & 0xFFFFFFFF),
+                          np.uint32(rng_seed & 0xFFFFFFFF), np.uint32((rng_seed >> 32) & 0xFFFFFFFF))
+    words = np.stack(words, axis=0)
+    u = words[i & 3, np.arange(n)] if n else np.zeros(0, dtype=np.uint32)
+    return mulhi_range(u, np.full(n, num_nodes, dtype=np.uint64)).astype(np.int64)

@@ -109,8 +109,8 @@ def test_train_epoch_matches_step_loop(dev):
     assert int(ea.step_dev) == 5
 
 
-@pytest.mark.parametrize("supervised_only", [True, False])
-def test_supervised_trainer_runs_and_learns(dev, supervised_only):
+@pytest.mark.parametrize("supervised_only,use_engine", [(True, None), (False, None), (False, True)])
+def test_supervised_trainer_runs_and_learns(dev, supervised_only, use_engine):
     from graphsage_amd import settings
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import UniformLoader
@@ -125,10 +125,10 @@ def test_supervised_trainer_runs_and_learns(dev, supervised_only):
     try:
         tr = SupervisedGraphSageTrainerForNodeLevelTask(
             data, UniformLoader, loss_fn=F.cross_entropy, model=model, optimizer=opt, num_epochs=3, device=dev,
-            k1=6, k2=4, dataset_name='planted', supervised_only=supervised_only)
+            k1=6, k2=4, dataset_name='planted', supervised_only=supervised_only, use_engine=use_engine)
     finally:
         dataloader_kwargs.update(old)
-    assert (tr.engine is not None) == supervised_only
+    assert (tr.engine is not None) == (supervised_only or bool(use_engine))
     best = tr.run(verbose=False)
     assert set(best) >= {'loss', 'val_acc', 'val_f1', 'test_acc', 'test_f1', 'train_time', 'test_time'}
     assert best['val_f1'] == best['val_acc'] and best['test_f1'] > 0.6
@@ -165,3 +165,50 @@ def test_fig2a_harness(dev, aggregator):
     assert set(out) >= {'test_time', 'train_time'}
     assert out['engine'] == (aggregator == "mean")
     assert out['train_time'] > 0 and out['test_time'] > 0 and out['test_acc'] > 0.5
+
+
+def test_engine_trainer_step_with_unsup_term_matches_oracle(dev):
+    """f-2 on the engine: loss = CE + unsupervised term (three forwards over one sampled batch,
+    trainers/node_level_graphsage_trainers.py:41 + base_trainers.py:170-181), gradients and the
+    Adam step against the CPU oracle.  Positive / negative ids are bit-exact restatements."""
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = _dataset()[0]
+    B, fan, lr, seed = 48, [5, 4], 1e-2, 17
+    layers = make_layers([24, 16, 5], "mean", 9)
+    model = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
+    load_layers(model, layers)
+    graph = device_graph(data)
+    engine = SageTrainEngine(model, NeighborSampler(data, fan, seed=seed), graph.features(data),
+                             graph.labels(data), B, lr=lr, unsup=True, keep_grads=True)
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), data.num_nodes)
+    train = data.train_mask.nonzero().view(-1)
+    params = [{k: v.clone() for k, v in p.items()} for p in layers]
+    state = [{k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()} for p in params]
+    for step in range(1, 4):
+        seeds, counter = train[(step - 1) * B:step * B], 200 + step
+        loss = engine.step(seeds.to(dev), counter=counter)
+        node, src, dst, _, _, _ = sampler.neighbor_sample(c0, r0, seeds.numpy(), fan, seed, counter)
+        nb = len(node)
+        pos = sampler.random_neighbor(c0, r0, node, seed, counter)
+        neg = sampler.random_nodes(data.num_nodes, nb, seed, counter)
+        assert engine.pos_id[:nb].cpu().numpy().tolist() == pos.tolist()
+        assert engine.neg_id[:nb].cpu().numpy().tolist() == neg.tolist()
+        leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+        ei = torch.from_numpy(np.stack([src, dst]))
+        outs = [sage_ref.graphsage_forward(data.x[torch.from_numpy(ids)], ei, leaf)[:B] for ids in (node, pos, neg)]
+        want = F.cross_entropy(outs[0], data.y[torch.from_numpy(node[:B])]) + sage_ref.unsup_loss(*outs)
+        want.backward()
+        torch.testing.assert_close(loss.cpu(), want.detach().view(1), rtol=1e-5, atol=1e-6)
+        for m, lf in zip(model.layers, leaf):
+            torch.testing.assert_close(engine.gviews[m.lin_l.weight].cpu(), lf["lin_l"].grad, rtol=1e-3, atol=1e-6)
+            torch.testing.assert_close(engine.gviews[m.lin_r.weight].cpu(), lf["lin_r"].grad, rtol=1e-3, atol=1e-6)
+        for p, lf, st in zip(params, leaf, state):
+            for k in p:
+                p[k], m1, v1 = sage_ref.adam_ref(p[k], lf[k].grad, st[k][0], st[k][1], step, lr)
+                st[k] = (m1, v1)
+        for m, p in zip(model.layers, params):
+            torch.testing.assert_close(m.lin_l.weight.detach().cpu(), p["lin_l"], rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(m.lin_r.weight.detach().cpu(), p["lin_r"], rtol=1e-4, atol=1e-6)
