@@ -159,3 +159,26 @@ def test_sampler_reddit_degree_structural(dev):
     new = torch.arange(nn, device=dev) >= B
     fp = first_pos[new]
     assert bool((fp[1:] > fp[:-1]).all())
+
+
+def test_random_nodes_and_bounded_random_neighbor(dev):
+    from graphsage_amd import ops
+    got = ops.random_nodes(12345, 3000, 5, 99, device=dev)
+    assert got.cpu().numpy().tolist() == sampler.random_nodes(12345, 3000, 5, 99).tolist()
+    ei = random_graph(300, 4000, 21, isolated=3)
+    colptr, row, _ = _csc_dev(ei, 300, dev)
+    c0, r0, _ = csc.to_csc(ei, 300)
+    start = np.random.default_rng(0).integers(0, 300, 500)
+    # device-side count: only the first 123 entries are walked, the rest of `out` is untouched
+    out = torch.full((500,), -7, dtype=torch.int64, device=dev)
+    bad = torch.from_numpy(start).to(dev)
+    bad[200:] = 10 ** 12                       # ids outside the graph beyond the count: never read
+    ops.random_neighbor(colptr, row, bad, 4, 6, out=out, checked=False, num_dev=torch.tensor([123], device=dev))
+    want = sampler.random_neighbor(c0, r0, start[:123], 4, 6)
+    assert out[:123].cpu().numpy().tolist() == want.tolist()
+    assert bool((out[123:] == -7).all())
+    # an id outside the graph inside the count yields 0 and touches no memory
+    bad[5] = -3
+    bad[6] = 300
+    ops.random_neighbor(colptr, row, bad, 4, 6, out=out, checked=False, num_dev=torch.tensor([123], device=dev))
+    assert int(out[5]) == 0 and int(out[6]) == 0 and int(out[7]) == int(want[7])

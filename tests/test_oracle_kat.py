@@ -181,3 +181,13 @@ def test_lstm_aggregate_ref_uses_torch_lstmcell_semantics():
     h2, _ = cell(torch.cat([x[0], x[0], x[0]]).unsqueeze(0))
     assert torch.allclose(out[0], h0.squeeze(0), atol=1e-6) and torch.allclose(out[2], h2.squeeze(0), atol=1e-6)
     assert bool((out[1] == 0).all()) and bool((out[3] == 0).all())
+
+
+def test_random_nodes_range_and_uniformity():
+    a = sampler.random_nodes(1000, 5000, 3, 7)
+    assert a.min() >= 0 and a.max() < 1000 and a.dtype == np.int64
+    assert a.tolist() == sampler.random_nodes(1000, 5000, 3, 7).tolist()          # a pure function
+    assert a[:100].tolist() == sampler.random_nodes(1000, 100, 3, 7).tolist()     # prefix-consistent
+    assert a.tolist() != sampler.random_nodes(1000, 5000, 3, 8).tolist()
+    counts = np.bincount(a // 100, minlength=10)                                   # 10 bins, expect 500 each
+    assert ((counts - 500.0) ** 2 / 500.0).sum() < 30.0                            # chi^2, 9 dof
