@@ -278,7 +278,7 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/gather_traffic.json"
-            roofline = {"bound": "hbm", "kernel": "gather_reduce_fwd_kernel (layer 0, mean, node_map)",
+            roofline = {"bound": "hbm", "kernel": f"gather_reduce_fwd_kernel (layer 0, {args.aggregator}, node_map)",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(float(ms.mean()) * 1e3, 2),

@@ -19,7 +19,7 @@ import torch
 from . import _lib, ops
 from .dist import all_reduce_flat
 
-_REDUCE = {'mean': 'mean', 'sum': 'sum'}
+_REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max'}
 
 
 def flatten_parameters(model, pad_to=16):
@@ -162,6 +162,8 @@ class SageTrainEngine:
                     a['dy'] = padded(t_cap, fout)     # unsup: gradient w.r.t. the normalised logits
                 if i > 0:
                     a['dagg'] = padded(t_cap, fin)
+                    if self.reduce == 'max':   # the backward routes to the edge that attained the max
+                        a['argmax'] = torch.zeros((t_cap, fin), dtype=torch.int64, device=dev)
                 act.append(a)
             return act
         self.acts = [make_act() for _ in range(nvar)]
@@ -337,7 +339,8 @@ class SageTrainEngine:
                     self._gather_layer0(slot)
             else:
                 lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
-                                      num_targets_dev=t_dev, out=agg, want_argmax=False)
+                                      num_targets_dev=t_dev, out=agg, want_argmax=self.reduce == 'max',
+                                      argmax=a.get('argmax'))
             # supervised step: the logit layer accumulates its split-K partial sums into z, which
             # the fused loss kernel hands back zeroed (z starts as zeros): no fill kernel
             lib.linear_concat_fwd(agg, layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
@@ -399,7 +402,7 @@ class SageTrainEngine:
                 lib.linear_dinput2(a['dz'], layer.lin_r.weight, prev['dh'], layer.lin_l.weight, a['dagg'],
                                    m=t_cap, m_dev=t_dev)
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
-                                      num_targets_dev=t_dev)
+                                      argmax=a.get('argmax'), num_targets_dev=t_dev)
 
     def make_pos_neg(self, slot, counter):
         """unsup: positive = one uniform in-neighbour of every batch node in the full graph,

@@ -6,7 +6,7 @@ backward -> Adam, supervised term only, :38-46) and of one inference pass over t
 Same function names and return keys ('train_time' per batch, 'test_time' per full test pass).
 Timing differs on purpose: the reference wraps every batch in time.time() (:39,:47), which on a
 GPU measures launch time unless it synchronises; here the device is synchronised once per epoch
-and the epoch time is divided by the number of batches.  mean/sum models run on the static-shape
+and the epoch time is divided by the number of batches.  mean/sum/max models run on the static-shape
 engine; every other aggregator runs the module path (autograd Functions over the same kernels).
 
     python -m graphsage_amd.experiments.fig2a --dataset cora --aggregators mean max_pool
@@ -29,6 +29,14 @@ HIDDEN_CHANNELS, NUM_LAYERS, LEARNING_RATE, BATCH_SIZE = 256, 2, 1e-3, 512
 
 def load_dataset(name):
     name = name.lower()
+    if name == 'reddit-shaped':
+        # timing runs: Reddit's SHAPE generated on the device (random features and labels: the
+        # accuracy it reports is chance level by construction), with Reddit's split sizes
+        from ..datasets.synthetic import SHAPES, SyntheticDataset, _masks, reddit_like_device
+        n, e, f, c, tr, va, te = SHAPES['Reddit']
+        data = reddit_like_device(n, e, f, c, seed=0, device=settings.DEVICE)
+        _masks(data, tr, va, te, 0)
+        return SyntheticDataset([data], c)
     if name == 'reddit':
         return Reddit(None)
     if name in {'cora', 'citeseer', 'pubmed'}:
@@ -89,7 +97,7 @@ def run(aggregator, dataset=None, num_epochs=None, batch_size=BATCH_SIZE, k1=K1,
     engine = None
     n_train = train_loader._idx_dev.numel()
     if use_engine is None:
-        use_engine = aggregator in ('mean', 'sum') and n_train >= batch_size
+        use_engine = aggregator in ('mean', 'sum', 'max') and n_train >= batch_size
     if use_engine:
         from ..engine import SageTrainEngine
         graph = train_loader.neighbor_sampler.graph
@@ -126,10 +134,13 @@ def main():
     ap.add_argument('--dataset', default='cora')
     ap.add_argument('--aggregators', nargs='+', default=['mean', 'max_pool'])
     ap.add_argument('--epochs', type=int, default=2)
+    ap.add_argument('--module-path', action='store_true', help='never use the static-shape engine')
     a, _ = ap.parse_known_args()
     ds = load_dataset(a.dataset)
     for agg in a.aggregators:
-        print(json.dumps({'aggregator': agg, **get(agg, dataset=ds, num_epochs=a.epochs, verbose=False).run()}))
+        kw = {'use_engine': False} if a.module_path else {}
+        print(json.dumps({'aggregator': agg, **get(agg, dataset=ds, num_epochs=a.epochs, verbose=False, **kw).run()}),
+              flush=True)
 
 
 if __name__ == '__main__':

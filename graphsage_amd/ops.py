@@ -276,7 +276,7 @@ def gather_rows(table, index, num_rows=None, num_rows_dev=None, out=None, checke
 
 # ------------------------------------------------------------------------------- a-5
 def gather_reduce_fwd(x, seg_ptr, src, num_targets, reduce, node_map=None,
-                      num_targets_dev=None, out=None, want_argmax=None):
+                      num_targets_dev=None, out=None, want_argmax=None, argmax=None):
     """scatter(x[src], dst, reduce) over target segments, fused
     (reference layers/sage.py:136-137 + :209-210).  Returns (out, argmax or None)."""
     lib = _lib.load()
@@ -293,9 +293,13 @@ def gather_reduce_fwd(x, seg_ptr, src, num_targets, reduce, node_map=None,
     red = REDUCE[reduce]
     if want_argmax is None:
         want_argmax = red == 2
-    argmax = None
     if red == 2 and want_argmax:
-        argmax = torch.empty((T, F), dtype=torch.int64, device=x.device)
+        if argmax is None:
+            argmax = torch.empty((T, F), dtype=torch.int64, device=x.device)
+        elif argmax.shape != (T, F) or not argmax.is_contiguous():
+            raise RuntimeError("gather_reduce_fwd: argmax buffer must be a contiguous [T,F] int64 tensor")
+    else:
+        argmax = None
     rc = lib.sage_gather_reduce_fwd(xp, ld_x, _vec(node_map, torch.int64, "node_map", allow_none=True),
                                     _vec(seg_ptr, torch.int64, "seg_ptr"),
                                     _vec(src, torch.int64, "src"), T,
