@@ -76,10 +76,8 @@ class SAGE(torch.nn.Module):
             num_dst = int(size[1])
         else:
             num_dst = int(edge_index[1].max()) + 1 if edge_index.numel() else 0
-        if self.aggregator == 'gcn':
-            # reference layers/sage.py:114-117: one self-loop per target that has an in-edge
-            roots = torch.unique(edge_index[1])
-            edge_index = torch.cat([edge_index, torch.stack([roots, roots], dim=0)], dim=1)
+        # (gcn's self-loops, reference layers/sage.py:114-117, are applied arithmetically in
+        # apply_plan: the edge list is not rewritten)
         plan = SF.plan_for(edge_index, x_src.size(0), num_dst)
         return self.apply_plan(x_src, x_dst, plan, num_dst, relu=False)
 
@@ -107,8 +105,22 @@ class SAGE(torch.nn.Module):
                 feats = SF.linear_concat(x_src, self.pool.weight, bias=self.pool.bias, relu=True,
                                          rows1=node_map, m=n_rows)
                 fmap = None
-            agg = SF.gather_reduce(feats, plan.seg_ptr, plan.src, num_targets,
-                                   _REDUCE[self.aggregator], node_map=fmap)
+            if self.aggregator == 'gcn':
+                # mean over the neighbours and ONE self-loop for every target that has an in-edge
+                # (reference layers/sage.py:114-117 appends the loops to edge_index and scatters):
+                # (sum_j x_j + x_t) / (deg_t + 1) if deg_t > 0 else 0 — same values, same order of
+                # summation (the loops are appended last), no edge list rewrite, prunable
+                s = SF.gather_reduce(feats, plan.seg_ptr, plan.src, num_targets, 'sum', node_map=fmap)
+                deg = (plan.seg_ptr[1:num_targets + 1] - plan.seg_ptr[:num_targets]).to(s.dtype).unsqueeze(1)
+                if node_map is None:
+                    self_rows = x_src[:num_targets]
+                else:
+                    from .. import ops
+                    self_rows = ops.gather_rows(x_src, node_map[:num_targets], checked=True)  # sampler ids
+                agg = torch.where(deg > 0, (s + self_rows) / (deg + 1.0), torch.zeros_like(s))
+            else:
+                agg = SF.gather_reduce(feats, plan.seg_ptr, plan.src, num_targets,
+                                       _REDUCE[self.aggregator], node_map=fmap)
         if self.root_weight and x_dst is not None:
             z = SF.linear_concat(agg, self.lin_l.weight, x_dst, self.lin_r.weight,
                                  rows2=node_map, m=num_targets)

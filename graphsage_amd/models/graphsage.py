@@ -47,7 +47,7 @@ class GraphSAGE(torch.nn.Module):
     def forward(self, x, edge_index):
         plan = getattr(edge_index, '_sage_plan', None)
         prunable = (self.prune_to_seeds and plan is not None and plan.hop_nodes is not None
-                    and self.aggregator != 'gcn' and plan.num_src == x.size(0))
+                    and plan.num_src == x.size(0))
         if not prunable:
             for i, layer in enumerate(self.layers):
                 x = layer(x, edge_index)
@@ -68,7 +68,7 @@ class GraphSAGE(torch.nn.Module):
         materialising batch.x: layer 0 gathers from the global feature table through the
         batch's node vector."""
         plan = batch.edge_index._sage_plan
-        if plan.table is None or self.aggregator == 'gcn':
+        if plan.table is None:
             return self.forward(batch.x, batch.edge_index)[:batch.batch_size]
         L = len(self.layers)
         x = plan.table
