@@ -278,10 +278,18 @@ def main():
                 with open(tpath) as f:
                     tj = json.load(f)
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/gather_traffic.json"
+            # what an empty event pair measures on this stream (not subtracted from anything: the
+            # rocprofv3 trace under profiles/ times the kernel alone and reads ~4 us less)
+            eb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+            for a0, b0 in eb:
+                a0.record()
+                b0.record()
+            torch.cuda.synchronize()
+            bracket_us = sum(a0.elapsed_time(b0) for a0, b0 in eb) / len(eb) * 1e3
             roofline = {"bound": "hbm", "kernel": f"gather_reduce_fwd_kernel (layer 0, {args.aggregator}, node_map)",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
+                        "avg_launch_us": round(float(ms.mean()) * 1e3, 2), "empty_event_pair_us": round(bracket_us, 2),
                         "algorithmic_bytes_per_launch": int(bytes_sum / args.steps), "row_stride_floats": int(ld)}
         # Informational only (never `value`): the same step with overlap_gather — layer-0 gather of
         # batch i+1 on the side stream beside the forward GEMM of batch i — measured right after
