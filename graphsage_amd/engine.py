@@ -183,8 +183,8 @@ class SageTrainEngine:
                                                  for _ in range(self.nslots - 1)]
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.row_loss = torch.zeros(self.B, dtype=torch.float32, device=dev)
-        # running sums of the sampler's state block over computed batches (batch sizes; a non-zero
-        # ST_ERROR sum means some batch reported an error)
+        # running sums of the sampler's state block over SAMPLED batches (batch sizes; a non-zero
+        # ST_ERROR sum means some batch reported an error); accumulated on the sampler's stream
         self.state_sum = torch.zeros(ops.STATE_WORDS, dtype=torch.int64, device=dev)
         self.counter = 0
         self.graphs = None
