@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-variant", action="store_true",
                     help="skip the extra (untimed for `value`) measurement of the overlap_gather schedule")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
+    ap.add_argument("--bracket-probe", action="store_true",
+                    help="record the probe's events around the gather launch instead of attaching them to it")
     ap.add_argument("--overlap-gather", action="store_true",
                     help="run the layer-0 gather of batch s+1 on the side stream during batch s")
     ap.add_argument("--variant", default="fig2a", choices=["fig2a", "trainer", "trainer-module"],
@@ -152,11 +154,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (graphsage_amd has no CPU path)")
+    if os.environ.get("SAGE_BENCH_WATCHDOG"):
+        # debugging aid: dump every thread's Python stack and exit if the run takes this long
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SAGE_BENCH_WATCHDOG"]), exit=True)
+    # Rehearsal of the N > 1 path on a ONE-GPU box (never what the driver runs): with
+    # SAGE_BENCH_BACKEND=gloo every rank uses cuda:0 and the gradient all-reduce goes over gloo
+    # (RCCL refuses two ranks on one device).  The number it prints is not a scaling result.
+    backend = os.environ.get("SAGE_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
@@ -202,20 +217,30 @@ def main():
     def counter_of(step):
         return step * world + rank
 
+    # Roofline probe: one HIP event pair per timed step, attached to the launch of the layer-0
+    # gather itself (hipExtLaunchKernelGGL start / stop events through sage_gather_reduce_fwd_timed):
+    # their elapsed time is that kernel's own duration on its stream.  (--bracket-probe records the
+    # pair around the launch instead: two extra markers, ~5 us more on this platform.)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     probe = not args.no_probe
+    attached = probe and not args.bracket_probe
+    if attached:
+        for a0, b0 in ev:          # torch creates the hipEvent_t on the first record
+            a0.record()
+            b0.record()
+        ev_handles = [(a0.cuda_event, b0.cuda_event) for a0, b0 in ev]
     use_graph = args.graph and not args.no_graph
     cur = {"i": 0}
 
     if use_graph:
         # HIP-graph replay: batch b = seeds mine[b*B:(b+1)*B], Philox counter rank + b*world
         engine.capture(mine, counter0=rank, counter_stride=world, split_gather=probe)
-        before = (lambda: ev[cur["i"]][0].record()) if probe else None
-        after = (lambda: ev[cur["i"]][1].record()) if probe else None
+        before = (lambda: ev[cur["i"]][0].record()) if (probe and not attached) else None
+        after = (lambda: ev[cur["i"]][1].record()) if (probe and not attached) else None
 
         def run_step(s, timed):
             if timed:
-                engine.replay(before, after)
+                engine.replay(before, after, ev_handles[cur["i"]] if attached else None)
             else:
                 engine.replay()
     else:
@@ -225,9 +250,10 @@ def main():
             engine.prefetch(seeds_of(d), counter_of(d))
 
         def run_step(s, timed):
-            b = (lambda: ev[cur["i"]][0].record()) if (probe and timed) else None
-            a = (lambda: ev[cur["i"]][1].record()) if (probe and timed) else None
-            engine.pipelined_step(seeds_of(s + depth), counter_of(s + depth), b, a)
+            b = (lambda: ev[cur["i"]][0].record()) if (probe and timed and not attached) else None
+            a = (lambda: ev[cur["i"]][1].record()) if (probe and timed and not attached) else None
+            engine.pipelined_step(seeds_of(s + depth), counter_of(s + depth), b, a,
+                                  ev_handles[cur["i"]] if (attached and timed) else None)
 
     for s in range(args.warmup):
         run_step(s, False)
@@ -289,7 +315,10 @@ def main():
             roofline = {"bound": "hbm", "kernel": f"gather_reduce_fwd_kernel (layer 0, {args.aggregator}, node_map)",
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                        "avg_launch_us": round(float(ms.mean()) * 1e3, 2), "empty_event_pair_us": round(bracket_us, 2),
+                        "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
+                        "timing": ("HIP start/stop events attached to each launch (hipExtLaunchKernelGGL)" if attached
+                                   else "HIP events recorded around each launch"),
+                        "empty_event_pair_us": round(bracket_us, 2),
                         "algorithmic_bytes_per_launch": int(bytes_sum / args.steps), "row_stride_floats": int(ld)}
         # Informational only (never `value`): the same step with overlap_gather — layer-0 gather of
         # batch i+1 on the side stream beside the forward GEMM of batch i — measured right after

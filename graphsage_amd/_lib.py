@@ -33,6 +33,8 @@ SIGNATURES = {
     "sage_gather_rows": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, c_int64, _P]),
     "sage_gather_reduce_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int,
                                        _P, c_int64, _P, _P]),
+    "sage_gather_reduce_fwd_timed": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int,
+                                             _P, c_int64, _P, _P, _P, _P]),
     "sage_gather_reduce_bwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int,
                                        _P, c_int64, _P]),
     "sage_coo_to_csr_workspace_bytes": (c_size_t, [c_int64, c_int64]),

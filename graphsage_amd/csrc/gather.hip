@@ -16,6 +16,8 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace sage {
@@ -375,22 +377,38 @@ extern "C" int sage_gather_rows(const void* table, sage_i64 ld_table, const sage
 
 namespace {
 
+struct LaunchEvents {
+  hipEvent_t start, stop;
+};
+
 template <int VEC, int NV>
 int launch_fwd(const float* x, int64_t ld_x, const int64_t* node_map, const int64_t* seg_ptr,
                const int64_t* src, int64_t nt, const int64_t* nt_dev, int nf, int reduce,
-               float* out, int64_t ld_out, int64_t* argmax, hipStream_t stream) {
+               float* out, int64_t ld_out, int64_t* argmax, const LaunchEvents& ev,
+               hipStream_t stream) {
   dim3 grid(static_cast<unsigned>(cdiv(nt, kWavesPerBlock)),
             static_cast<unsigned>(cdiv(nf, kWave * VEC * NV)));
+  // with events: the launch itself carries them (they read the dispatch's own start / end
+  // timestamps instead of the time between two markers around it)
+#define SAGE_LAUNCH_FWD(R)                                                                      \
+  do {                                                                                          \
+    if (ev.start != nullptr) {                                                                  \
+      hipExtLaunchKernelGGL((gather_reduce_fwd_kernel<VEC, NV, R>), grid, dim3(kBlock), 0,      \
+                            stream, ev.start, ev.stop, 0, x, ld_x, node_map, seg_ptr, src, nt,  \
+                            nt_dev, nf, out, ld_out, argmax);                                   \
+    } else {                                                                                    \
+      gather_reduce_fwd_kernel<VEC, NV, R><<<grid, kBlock, 0, stream>>>(                        \
+          x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, out, ld_out, argmax);                \
+    }                                                                                           \
+  } while (0)
   if (reduce == SAGE_REDUCE_MEAN) {
-    gather_reduce_fwd_kernel<VEC, NV, SAGE_REDUCE_MEAN><<<grid, kBlock, 0, stream>>>(
-        x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, out, ld_out, argmax);
+    SAGE_LAUNCH_FWD(SAGE_REDUCE_MEAN);
   } else if (reduce == SAGE_REDUCE_SUM) {
-    gather_reduce_fwd_kernel<VEC, NV, SAGE_REDUCE_SUM><<<grid, kBlock, 0, stream>>>(
-        x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, out, ld_out, argmax);
+    SAGE_LAUNCH_FWD(SAGE_REDUCE_SUM);
   } else {
-    gather_reduce_fwd_kernel<VEC, NV, SAGE_REDUCE_MAX><<<grid, kBlock, 0, stream>>>(
-        x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, out, ld_out, argmax);
+    SAGE_LAUNCH_FWD(SAGE_REDUCE_MAX);
   }
+#undef SAGE_LAUNCH_FWD
   SAGE_CHECK_LAUNCH("gather_reduce_fwd_kernel");
   return SAGE_OK;
 }
@@ -399,26 +417,24 @@ template <int VEC>
 int dispatch_fwd_nv(int nv, const float* x, int64_t ld_x, const int64_t* node_map,
                     const int64_t* seg_ptr, const int64_t* src, int64_t nt, const int64_t* nt_dev,
                     int nf, int reduce, float* out, int64_t ld_out, int64_t* argmax,
-                    hipStream_t stream) {
+                    const LaunchEvents& ev, hipStream_t stream) {
   switch (nv) {
     case 1:
-      return launch_fwd<VEC, 1>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+      return launch_fwd<VEC, 1>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, ev, stream);
     case 2:
-      return launch_fwd<VEC, 2>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+      return launch_fwd<VEC, 2>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, ev, stream);
     case 3:
-      return launch_fwd<VEC, 3>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+      return launch_fwd<VEC, 3>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, ev, stream);
     default:
-      return launch_fwd<VEC, 4>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, stream);
+      return launch_fwd<VEC, 4>(x, ld_x, node_map, seg_ptr, src, nt, nt_dev, nf, reduce, out, ld_out, argmax, ev, stream);
   }
 }
 
-}  // namespace
-
-extern "C" int sage_gather_reduce_fwd(const float* x, sage_i64 ld_x, const sage_i64* node_map,
-                                      const sage_i64* seg_ptr, const sage_i64* src,
-                                      sage_i64 num_targets, const sage_i64* num_targets_dev,
-                                      int num_features, int reduce, float* out, sage_i64 ld_out,
-                                      sage_i64* argmax, void* stream_) {
+int gather_reduce_fwd_impl(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                           const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                           const sage_i64* num_targets_dev, int num_features, int reduce,
+                           float* out, sage_i64 ld_out, sage_i64* argmax, const LaunchEvents& ev,
+                           void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX,
                SAGE_EINVAL, "sage_gather_reduce_fwd: unknown reduce %d", reduce);
@@ -435,12 +451,41 @@ extern "C" int sage_gather_reduce_fwd(const float* x, sage_i64 ld_x, const sage_
   if (nv > 4) nv = 4;
   if (vec == 4)
     return dispatch_fwd_nv<4>(nv, x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
-                              num_features, reduce, out, ld_out, argmax, stream);
+                              num_features, reduce, out, ld_out, argmax, ev, stream);
   if (vec == 2)
     return dispatch_fwd_nv<2>(nv, x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
-                              num_features, reduce, out, ld_out, argmax, stream);
+                              num_features, reduce, out, ld_out, argmax, ev, stream);
   return dispatch_fwd_nv<1>(nv, x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
-                            num_features, reduce, out, ld_out, argmax, stream);
+                            num_features, reduce, out, ld_out, argmax, ev, stream);
+}
+
+}  // namespace
+
+extern "C" int sage_gather_reduce_fwd(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                                      const sage_i64* seg_ptr, const sage_i64* src,
+                                      sage_i64 num_targets, const sage_i64* num_targets_dev,
+                                      int num_features, int reduce, float* out, sage_i64 ld_out,
+                                      sage_i64* argmax, void* stream) {
+  return gather_reduce_fwd_impl(x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
+                                num_features, reduce, out, ld_out, argmax,
+                                LaunchEvents{nullptr, nullptr}, stream);
+}
+
+extern "C" int sage_gather_reduce_fwd_timed(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                                            const sage_i64* seg_ptr, const sage_i64* src,
+                                            sage_i64 num_targets, const sage_i64* num_targets_dev,
+                                            int num_features, int reduce, float* out,
+                                            sage_i64 ld_out, sage_i64* argmax, void* start_event,
+                                            void* stop_event, void* stream) {
+  SAGE_REQUIRE(start_event != nullptr && stop_event != nullptr, SAGE_EINVAL,
+               "sage_gather_reduce_fwd_timed: NULL event");
+  SAGE_REQUIRE(num_targets > 0, SAGE_EINVAL,
+               "sage_gather_reduce_fwd_timed: nothing to launch (num_targets = 0), the events would stay unrecorded");
+  return gather_reduce_fwd_impl(x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
+                                num_features, reduce, out, ld_out, argmax,
+                                LaunchEvents{static_cast<hipEvent_t>(start_event),
+                                             static_cast<hipEvent_t>(stop_event)},
+                                stream);
 }
 
 extern "C" int sage_gather_reduce_bwd(const float* dout, sage_i64 ld_dout, const sage_i64* seg_ptr,

@@ -20,11 +20,39 @@ def batch_counter(epoch, batches_per_epoch, batch, rank, world_size):
     return (epoch * batches_per_epoch + batch) * world_size + rank
 
 
+class _Done:
+    """Work-like handle of a collective that has already completed on the caller's stream."""
+
+    def wait(self):
+        return True
+
+
+_staging = {}
+
+
+def _all_reduce_staged(flat_grad, group):
+    """gloo with a DEVICE tensor (tests and rehearsals with several ranks on one GPU; the
+    production backend is nccl): stage through pinned host memory on the caller's stream and
+    run the collective on the host copy.  ProcessGroupGloo's own device path (a pool of 32
+    side streams, one per collective) was seen to hang here with two ranks sharing a GPU."""
+    key = (flat_grad.numel(), flat_grad.dtype)
+    host = _staging.get(key)
+    if host is None:
+        host = _staging[key] = torch.empty(flat_grad.numel(), dtype=flat_grad.dtype, pin_memory=True)
+    host.copy_(flat_grad.reshape(-1), non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+    flat_grad.reshape(-1).copy_(host, non_blocking=True)     # ordered on the current stream
+
+
 def all_reduce_flat(flat_grad, group=None, async_op=False):
     """Sum the flat gradient buffer over ranks (the mean's 1/world is fused into Adam).
     async_op=True returns the work handle (None when there is nothing to reduce): the collective
     runs on the backend's own stream and handle.wait() orders the current stream after it."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if flat_grad.is_cuda and dist.get_backend(group) == "gloo":
+            _all_reduce_staged(flat_grad, group)
+            return _Done() if async_op else flat_grad
         work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return work if async_op else flat_grad
     return None if async_op else flat_grad

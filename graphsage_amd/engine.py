@@ -285,14 +285,35 @@ class SageTrainEngine:
         else:
             _lib.replay(tape)
 
-    def gather_layer0(self, slot=0, stream=None):
-        self._taped('gather0', slot, lambda: self._gather_layer0(slot), stream)
+    def gather_layer0(self, slot=0, stream=None, events=None):
+        """Layer-0 gather of the batch in `slot`.  events = (start, stop) raw HIP event handles:
+        the launch carries them (sage_gather_reduce_fwd_timed), for a caller that measures this
+        kernel (bench.py's roofline probe)."""
+        if events is None:
+            self._taped('gather0', slot, lambda: self._gather_layer0(slot), stream)
+            return
+        cur = torch.cuda.current_stream()
+        key = ('gather0t', slot, (stream or cur).cuda_stream)
+        entry = self._tapes.get(key)
+        if entry is None:
+            if stream is not None and stream != cur:
+                with torch.cuda.stream(stream), _lib.recording() as tape:
+                    self._gather_layer0(slot, events)
+            else:
+                with _lib.recording() as tape:
+                    self._gather_layer0(slot, events)
+            (fn, args, name), = tape
+            self._tapes[key] = (fn, list(args), name)
+            return
+        fn, args, name = entry
+        args[12], args[13] = int(events[0]), int(events[1])     # same pointers, this step's events
+        _lib.check(fn(*args), name)
 
-    def _gather_layer0(self, slot):
+    def _gather_layer0(self, slot, events=None):
         a, buf = self.act[0], self.bufs[slot]
         ops.gather_reduce_fwd(self.features, buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
                               node_map=buf.node, num_targets_dev=self.n_dev[slot][a['hop']],
-                              out=self.agg0[slot], want_argmax=False)
+                              out=self.agg0[slot], want_argmax=False, events=events)
 
     def forward_backward(self, slot=0, skip_gather0=False):
         self.last_slot = slot
@@ -449,19 +470,19 @@ class SageTrainEngine:
         return self.loss
 
     # ------------------------------------------------------------------ pipelined, eager
-    def _side_gather(self, slot, before_gather, after_gather):
+    def _side_gather(self, slot, before_gather, after_gather, gather_events=None):
         if before_gather is None and after_gather is None:
-            self.gather_layer0(slot, stream=self.side)
+            self.gather_layer0(slot, stream=self.side, events=gather_events)
         else:     # the hooks record events on the current stream
             with torch.cuda.stream(self.side):
                 if before_gather is not None:
                     before_gather()
-                self.gather_layer0(slot)
+                self.gather_layer0(slot, events=gather_events)
                 if after_gather is not None:
                     after_gather()
         self.gathered[slot] = True
 
-    def prefetch(self, seeds, counter, before_gather=None, after_gather=None):
+    def prefetch(self, seeds, counter, before_gather=None, after_gather=None, gather_events=None):
         """Sample `seeds` on the side stream into the next slot of the ring.  Call it `depth`
         times before the first pipelined_step()."""
         n = self.n_pref
@@ -487,13 +508,17 @@ class SageTrainEngine:
             self.ready[slot].record(self.side)
         elif self.n_pref - self.n_comp == 1:
             # nothing is computing: no GEMM to hide behind, gather right away
-            self._side_gather(slot, before_gather, after_gather)
+            self._side_gather(slot, before_gather, after_gather, gather_events)
             self.ready[slot].record(self.side)
 
-    def pipelined_step(self, next_seeds=None, next_counter=None, before_gather=None, after_gather=None):
+    def pipelined_step(self, next_seeds=None, next_counter=None, before_gather=None, after_gather=None,
+                       gather_events=None):
         """Train on the oldest prefetched batch while the side stream prepares the following ones:
         the sampler of batch i+depth and, with overlap_gather, the layer-0 gather of batch i+1
-        (held back until this step has started, so that it runs beside the forward GEMM)."""
+        (held back until this step has started, so that it runs beside the forward GEMM).
+        Measurement hooks for the layer-0 gather this call launches: before_gather / after_gather
+        are called around it on its stream; gather_events = (start, stop) raw HIP event handles
+        are attached to the launch itself (gather_layer0)."""
         if self.n_pref == self.n_comp:
             raise RuntimeError("pipelined_step() needs a prefetch() first")
         i = self.n_comp
@@ -509,7 +534,7 @@ class SageTrainEngine:
                 self.started.record(main)
                 self.side.wait_event(self.started)
                 q = (i + 1) % self.nslots
-                self._side_gather(q, before_gather, after_gather)
+                self._side_gather(q, before_gather, after_gather, gather_events)
                 self.ready[q].record(self.side)
         else:
             if i > self.main_ready_seq:
@@ -519,7 +544,7 @@ class SageTrainEngine:
                 self.main_ready_seq = newest
             if before_gather is not None:
                 before_gather()
-            self.gather_layer0(p)
+            self.gather_layer0(p, events=gather_events)
             if after_gather is not None:
                 after_gather()
         self.n_comp = i + 1
@@ -656,7 +681,7 @@ class SageTrainEngine:
         self._first_replay = True
         return self
 
-    def replay(self, before_gather=None, after_gather=None):
+    def replay(self, before_gather=None, after_gather=None, gather_events=None):
         gs, gc, ga = self.graphs
         p = self.use
         main = torch.cuda.current_stream()
@@ -670,7 +695,7 @@ class SageTrainEngine:
         if self.split_gather:
             if before_gather is not None:
                 before_gather()
-            self.gather_layer0(p)
+            self.gather_layer0(p, events=gather_events)
             if after_gather is not None:
                 after_gather()
         gc[p].replay()

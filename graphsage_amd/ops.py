@@ -276,9 +276,11 @@ def gather_rows(table, index, num_rows=None, num_rows_dev=None, out=None, checke
 
 # ------------------------------------------------------------------------------- a-5
 def gather_reduce_fwd(x, seg_ptr, src, num_targets, reduce, node_map=None,
-                      num_targets_dev=None, out=None, want_argmax=None, argmax=None):
+                      num_targets_dev=None, out=None, want_argmax=None, argmax=None, events=None):
     """scatter(x[src], dst, reduce) over target segments, fused
-    (reference layers/sage.py:136-137 + :209-210).  Returns (out, argmax or None)."""
+    (reference layers/sage.py:136-137 + :209-210).  Returns (out, argmax or None).
+    events = (start, stop) raw HIP event handles: the launch carries them, so that their
+    elapsed time is this kernel's own duration (measurement only)."""
     lib = _lib.load()
     xp, ld_x = _mat(x, "x")
     F = x.size(1)
@@ -300,12 +302,19 @@ def gather_reduce_fwd(x, seg_ptr, src, num_targets, reduce, node_map=None,
             raise RuntimeError("gather_reduce_fwd: argmax buffer must be a contiguous [T,F] int64 tensor")
     else:
         argmax = None
-    rc = lib.sage_gather_reduce_fwd(xp, ld_x, _vec(node_map, torch.int64, "node_map", allow_none=True),
-                                    _vec(seg_ptr, torch.int64, "seg_ptr"),
-                                    _vec(src, torch.int64, "src"), T,
-                                    _count(num_targets_dev, "num_targets_dev"), F, red, op, ld_out,
-                                    _p(argmax, torch.int64, "argmax", allow_none=True), _stream())
-    _lib.check(rc, "sage_gather_reduce_fwd")
+    head = (xp, ld_x, _vec(node_map, torch.int64, "node_map", allow_none=True),
+            _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), T,
+            _count(num_targets_dev, "num_targets_dev"), F, red, op, ld_out,
+            _p(argmax, torch.int64, "argmax", allow_none=True))
+    if events is None:
+        _lib.check(lib.sage_gather_reduce_fwd(*head, _stream()), "sage_gather_reduce_fwd")
+    else:
+        # raw hipEvent_t handles (e.g. torch.cuda.Event.cuda_event of events that exist already)
+        e0, e1 = (int(e) for e in events)
+        if not e0 or not e1:
+            raise RuntimeError("gather_reduce_fwd: events must be two created HIP events")
+        _lib.check(lib.sage_gather_reduce_fwd_timed(*head, c_void_p(e0), c_void_p(e1), _stream()),
+                   "sage_gather_reduce_fwd_timed")
     return out, argmax
 
 

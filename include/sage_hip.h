@@ -191,6 +191,19 @@ int sage_gather_reduce_fwd(const float* x, sage_i64 ld_x, const sage_i64* node_m
                            const sage_i64* num_targets_dev, int num_features, int reduce,
                            float* out, sage_i64 ld_out, sage_i64* argmax, void* stream);
 
+/* The same launch carrying two HIP events (hipEvent_t, created by the caller with timing
+ * enabled): the kernel is dispatched with hipExtLaunchKernelGGL, so that
+ * hipEventElapsedTime(start_event, stop_event) is the duration of THIS kernel (the dispatch's
+ * own start / end timestamps) rather than the distance between two markers recorded around it.
+ * Measurement only (bench.py's roofline probe); no counterpart in the reference.  Fails with
+ * SAGE_EINVAL when nothing would be launched (num_targets == 0). */
+int sage_gather_reduce_fwd_timed(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                                 const sage_i64* seg_ptr, const sage_i64* src,
+                                 sage_i64 num_targets, const sage_i64* num_targets_dev,
+                                 int num_features, int reduce, float* out, sage_i64 ld_out,
+                                 sage_i64* argmax, void* start_event, void* stop_event,
+                                 void* stream);
+
 /* Backward of the above w.r.t. x (autograd of scatter + index_select):
  *   sum : dx[src[e], :] += dout[t, :]            mean: += dout[t, :] / max(count_t, 1)
  *   max : dx[src[argmax[t,f]], f] += dout[t, f]  (argmax >= 0)

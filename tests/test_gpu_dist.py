@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 B, STEPS, FAN = 32, 4, [5, 3]
+LONG_STEPS = 80
 
 
 def _setup():
@@ -34,13 +35,15 @@ def _engine(data, model, dev, **kw):
                            graph.labels(data), B, lr=1e-2, **kw)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, long_run=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from graphsage_amd.dist import batch_counter, shard_seeds
     dev = torch.device("cuda:0")
     data, model, train = _setup()
+    if long_run:      # what bench.py does: many steps, the host never waits for the device
+        train = torch.randint(0, 1500, (2 * B * LONG_STEPS,), generator=torch.Generator().manual_seed(2))
     eng = _engine(data, model, dev, world_size=world, process_group=dist.group.WORLD)
     mine = shard_seeds(train, rank, world).to(dev)
     nb = mine.numel() // B
@@ -50,12 +53,27 @@ def _worker(rank, world, port, out):
     losses = []
     for b in range(nb):
         nxt = mine[(b + d) * B:(b + d + 1) * B] if b + d < nb else None
-        losses.append(float(eng.pipelined_step(nxt, batch_counter(0, nb, b + d, rank, world) if nxt is not None else None)))
-    assert int(eng.step_dev) == nb - 1        # the last Adam is deferred until flush()
+        loss = eng.pipelined_step(nxt, batch_counter(0, nb, b + d, rank, world) if nxt is not None else None)
+        losses.append(loss.clone() if long_run else float(loss))
+    if not long_run:
+        assert int(eng.step_dev) == nb - 1        # the last Adam is deferred until flush()
     eng.flush()
     torch.cuda.synchronize()
-    out[rank] = (eng.flat.cpu(), losses, int(eng.step_dev))
+    out[rank] = (eng.flat.cpu(), [float(x) for x in losses], int(eng.step_dev))
     dist.destroy_process_group()
+
+
+def test_engine_data_parallel_many_steps_no_host_sync(dev):
+    world = 2
+    out = mp.Manager().dict()
+    port = 29300 + (os.getpid() % 300)
+    mp.spawn(_worker, args=(world, port, out, True), nprocs=world, join=True)
+    flat0, loss0, steps0 = out[0]
+    flat1, loss1, steps1 = out[1]
+    assert steps0 == steps1 == LONG_STEPS
+    assert torch.equal(flat0, flat1)
+    assert all(x == x and 0.0 < x < 10.0 for x in loss0 + loss1)
+    assert sum(loss0[-8:]) < sum(loss0[:8])                # and it trains
 
 
 def test_engine_data_parallel_two_ranks(dev):

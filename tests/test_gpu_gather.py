@@ -112,6 +112,36 @@ def test_gather_reduce_node_map_and_device_count(dev):
     assert bool((buf[77:] == 7.0).all())
 
 
+def test_gather_reduce_timed_launch(dev):
+    """sage_gather_reduce_fwd_timed: same kernel, same output, and the two events attached to
+    the launch read a positive duration that is no longer than a pair recorded around it."""
+    from graphsage_amd import ops
+    T, S, N, F = 4000, 6000, 20000, 602
+    src, dst = _segments(T, 25, S, seed=9)
+    g = torch.Generator().manual_seed(4)
+    table = _padded(torch.randn(N, F, generator=g), dev, True)
+    node = torch.randperm(N, generator=g)[:S].to(dev)
+    seg_ptr = torch.zeros(T + 1, dtype=torch.int64)
+    seg_ptr[1:] = torch.bincount(dst, minlength=T).cumsum(0)
+    seg_ptr, src = seg_ptr.to(dev), src.to(dev)
+    want, _ = ops.gather_reduce_fwd(table, seg_ptr, src, T, "mean", node_map=node)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    for x in e:
+        x.record()                      # creates the hipEvent_t
+    torch.cuda.synchronize()
+    out = torch.zeros_like(want)
+    e[2].record()
+    ops.gather_reduce_fwd(table, seg_ptr, src, T, "mean", node_map=node, out=out,
+                          events=(e[0].cuda_event, e[1].cuda_event))
+    e[3].record()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    inner, outer = e[0].elapsed_time(e[1]), e[2].elapsed_time(e[3])
+    assert 0.0 < inner <= outer
+    with pytest.raises(RuntimeError):
+        ops.gather_reduce_fwd(table, seg_ptr, src, T, "mean", node_map=node, events=(0, 0))
+
+
 def test_gather_reduce_long_segments_and_kats(dev):
     from graphsage_amd import ops
     # one target with 1000 edges (several 64-edge chunks), duplicates counted twice, negatives
