@@ -35,8 +35,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--settle-steps", type=int, default=1500,
+                    help="untimed steps BEFORE the warm-up steps (set-up, not part of W or K): the first "
+                         "~0.5 s of launches of a fresh process run at half speed on the host side "
+                         "(lazy code-object loading, call-tape recording, and whatever the driver still "
+                         "does for a process that has just exited)")
     ap.add_argument("--workload", default="reddit", choices=sorted(SHAPES))
     ap.add_argument("--batch-size", type=int, default=512)
     ap.add_argument("--hidden", type=int, default=256)
@@ -255,7 +260,12 @@ def main():
             engine.pipelined_step(seeds_of(s + depth), counter_of(s + depth), b, a,
                                   ev_handles[cur["i"]] if (attached and timed) else None)
 
-    for s in range(args.warmup):
+    # set-up: settle (includes the probe's launch path, so that its call tapes exist), then W warm-up
+    base = max(args.settle_steps, 0)
+    for s in range(base):
+        cur["i"] = s % args.steps
+        run_step(s, s < 4 * engine.nslots)
+    for s in range(base, base + args.warmup):
         run_step(s, False)
     torch.cuda.synchronize()
     if world > 1:
@@ -264,8 +274,8 @@ def main():
     st0 = engine.state_sum.clone()
     setup_s = time.perf_counter() - t_setup
     t0 = time.perf_counter()
-    for s in range(args.warmup, args.warmup + args.steps):
-        cur["i"] = s - args.warmup
+    for s in range(base + args.warmup, base + args.warmup + args.steps):
+        cur["i"] = s - args.warmup - base
         run_step(s, True)
     engine.flush()                                 # data parallel: the last step's deferred Adam
     t_issued = time.perf_counter() - t0            # host-side enqueue time of the timed steps
@@ -365,7 +375,7 @@ def main():
                                                              "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},
             "roofline": roofline, "cpu_baseline": cpu, "variant_overlap_gather": variant,
-            "final_loss": round(loss, 5), "setup_s": round(setup_s, 1),
+            "final_loss": round(loss, 5), "setup_s": round(setup_s, 1), "settle_steps": base,
             "avg_nodes_per_batch": float(st[ops.ST_NODES]) / args.steps,
             "avg_edges_per_batch": float(st[ops.ST_EDGES]) / args.steps,
             "variant": args.variant, "hip_graph": use_graph, "host_enqueue_ms_per_step": round(t_issued / args.steps * 1e3, 4), "overlap_gather": bool(args.overlap_gather),

@@ -54,7 +54,7 @@ SIGNATURES = {
     "sage_lstm_cell0_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int, _P, c_int64, _P]),
     "sage_lstm_cell0_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, c_int, _P, c_int64, _P]),
     "sage_l2norm_relu_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int, _P, c_int64, _P, c_int64,
-                                     _P, _P]),
+                                     _P, c_int, _P]),
     "sage_l2norm_relu_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int64, _P, c_int,
                                      _P, c_int64, c_int, _P]),
     "sage_softmax_xent": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, c_int64,

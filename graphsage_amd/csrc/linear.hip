@@ -60,6 +60,10 @@ struct GemmArgs {
   int epilogue;            // SAGE_EPI_* flags
   int atomic_out;          // 1: atomicAdd into out (split-K / accumulate)
   int k_chunk;             // split-K: contraction elements per blockIdx.z (multiple of BK)
+  // stream-K (forward only): a 1-D grid of gridDim.x workgroups shares the K-steps of ALL tiles
+  // evenly; a workgroup walks a contiguous range of (tile, K-step) pairs, stores a tile it
+  // covers completely and adds the others with fp32 atomics (output zeroed beforehand)
+  int streamk;
   float* colsum;           // optional: colsum[m] += sum_k A(m,k) (dbias), only blockIdx.y == 0
   // batched mode (d-weight pair): seg[0] and seg[1] are two INDEPENDENT problems that share the
   // A operand; blockIdx.y < ny0 works on problem 0 (out, n), the rest on problem 1 (out2, n2)
@@ -201,6 +205,132 @@ struct TileLoader {
   }
 };
 
+// Forward operand (contraction dim contiguous) with up to TWO K-segments behind one pipeline:
+// the K-loop runs over "unified" steps 0 .. steps0+steps1-1, the first steps0 of them in segment
+// 0, so the loads of segment 1 are already in flight while the last steps of segment 0 multiply
+// (no second pipeline fill, and the row-map lookups of both segments are issued together before
+// the loop).  Everything that depends on the segment is a select on a wave-uniform condition —
+// no branch in the loop (see the K-loop notes in gemm_kernel).
+template <int MN, int VEC>
+struct DualLoader {
+  static constexpr int UNITS = MN * BK / VEC;
+  static constexpr int PASSES = UNITS / kThreads;
+  static constexpr int UPR = BK / VEC;
+  static_assert(PASSES >= 1, "tile too small for the thread block");
+  using VT = typename VecT<VEC>::type;
+
+  // (every member is indexed with compile-time constants only, and a segment-dependent value
+  // is selected AFTER both candidates were read into locals: a conditional expression over two
+  // array elements becomes a load through a selected pointer, which sends the whole struct to
+  // scratch memory)
+  VT va[PASSES], vb[PASSES];           // the two register sets
+  int64_t rowoff0[PASSES], rowoff1[PASSES];   // offset of the (clamped, mapped) row, per segment
+  const float* base0;
+  const float* base1;
+  int kbeg0, kend0, kbeg1, kend1;
+  int steps0;                          // K-steps of this piece that lie in segment 0
+
+  __device__ inline int trow(int p) const { return (threadIdx.x + p * kThreads) / UPR; }
+  __device__ inline int tcol(int p) const { return ((threadIdx.x + p * kThreads) % UPR) * VEC; }
+
+  // rows of the tile: fixed for every K-range of this tile
+  __device__ inline void begin(const Operand& o0, const Operand& o1, int64_t mn0, int64_t mn_lim) {
+    int64_t ids[PASSES], id0[PASSES], id1[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int64_t r = mn0 + trow(p);
+      ids[p] = r < mn_lim ? r : mn_lim - 1;
+    }
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) id0[p] = o0.rowmap != nullptr ? o0.rowmap[ids[p]] : ids[p];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) id1[p] = o1.rowmap != nullptr ? o1.rowmap[ids[p]] : ids[p];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      rowoff0[p] = id0[p] * o0.ld;
+      rowoff1[p] = id1[p] * o1.ld;
+    }
+    base0 = o0.p;
+    base1 = o1.p;
+  }
+
+  // contraction ranges [kb, ke) of the two segments for this piece; returns the number of K-steps
+  __device__ inline int range(int kb0, int ke0, int kb1, int ke1) {
+    const int n0 = ke0 > kb0 ? (ke0 - kb0 + BK - 1) / BK : 0;
+    const int n1 = ke1 > kb1 ? (ke1 - kb1 + BK - 1) / BK : 0;
+    const bool unused1 = n1 == 0;
+    // segment 1 unused: requests past the last step are addressed through it, keep it valid
+    base1 = unused1 ? base0 : base1;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int64_t r0 = rowoff0[p], r1 = rowoff1[p];
+      rowoff1[p] = unused1 ? r0 : r1;
+    }
+    kbeg0 = kb0; kend0 = ke0;
+    kbeg1 = unused1 ? kb0 : kb1;
+    kend1 = unused1 ? ke0 : ke1;
+    steps0 = n0;
+    return n0 + n1;
+  }
+
+  // Request the tile of unified step `step` (any step >= 0: addresses are clamped, the values of
+  // a step past the end are never stored).
+  template <int SET>
+  __device__ inline void issue(int step) {
+    typedef const VT __attribute__((address_space(1)))* GlobalVec;   // global, not flat
+    const bool s1 = step >= steps0;
+    const int k0a = kbeg0 + step * BK, k0b = kbeg1 + (step - steps0) * BK;
+    const int k0 = s1 ? k0b : k0a;
+    const int kea = kend0, keb = kend1;
+    const int kmax = ((s1 ? keb : kea) - 1) / VEC * VEC;
+    const float* ba = base0;
+    const float* bb = base1;
+    const float* b = s1 ? bb : ba;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int kk = k0 + tcol(p);
+      const int64_t r0 = rowoff0[p], r1 = rowoff1[p];
+      const float* src = b + (s1 ? r1 : r0) + (kk < kmax ? kk : kmax);
+      if constexpr (SET == 0) va[p] = *((GlobalVec)(src));
+      else vb[p] = *((GlobalVec)(src));
+    }
+  }
+
+  // write the tile requested by issue<SET>(step) into LDS as [mn][k]; the contraction tail of
+  // the step's segment is zeroed
+  template <int LDS_LD, int SET>
+  __device__ inline void store(int step, float* lds) const {
+    const bool s1 = step >= steps0;
+    const int k0a = kbeg0 + step * BK, k0b = kbeg1 + (step - steps0) * BK;
+    const int k0 = s1 ? k0b : k0a;
+    const int kea = kend0, keb = kend1;
+    const int ke = s1 ? keb : kea;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      VT x;
+      if constexpr (SET == 0) x = va[p];
+      else x = vb[p];
+      float e[VEC];
+      if constexpr (VEC == 4) { e[0] = x.x; e[1] = x.y; e[2] = x.z; e[3] = x.w; }
+      else if constexpr (VEC == 2) { e[0] = x.x; e[1] = x.y; }
+      else { e[0] = x; }
+      const int c0 = k0 + tcol(p);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (c0 + j >= ke) e[j] = 0.f;
+      }
+      float* dst = lds + trow(p) * LDS_LD + tcol(p);
+      if constexpr (VEC == 4) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f4v*>(dst) = f4v{e[0], e[1], e[2], e[3]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = e[j];
+      }
+    }
+  }
+};
+
 // 4 waves as 2 (M) x 2 (N); each wave owns (BM/2) x (BN/2) = TM x TN tiles of 32x32.
 template <bool A_KC, bool B_KC, int BM, int BN, int VEC>
 __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
@@ -226,14 +356,40 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
     const int64_t v = *g.m_dev;
     if (v < m_lim) m_lim = v;
   }
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM;
-  if (m0 >= m_lim) return;
-  int prob = 0, by = blockIdx.y;
+  // forward (both operands k-contiguous): both K-segments behind one pipeline, optional stream-K
+  constexpr bool kDual = A_KC && B_KC;
+  const unsigned bx = blockIdx.x, by_ = blockIdx.y, bz = blockIdx.z;
+  int64_t m0 = static_cast<int64_t>(bx) * BM;
+  int prob = 0, by = by_;
   if (g.batched && by >= g.ny0) {
     prob = 1;
     by -= g.ny0;
   }
-  const int64_t n0 = static_cast<int64_t>(by) * BN;
+  int64_t n0 = static_cast<int64_t>(by) * BN;
+  // stream-K state: this workgroup's range [sk_it, sk_end) of global K-steps, sk_S steps per tile
+  int64_t sk_it = 0, sk_end = 0;
+  int sk_S = 1, sk_S0 = 0, sk_tiles_n = 1, sk_u0 = 0, sk_u1 = 0;
+  bool sk_partial = false;
+  if constexpr (kDual) {
+    if (g.streamk) {
+      sk_S0 = (g.seg[0].k + BK - 1) / BK;
+      sk_S = sk_S0 + (g.nseg > 1 ? (g.seg[1].k + BK - 1) / BK : 0);
+      sk_tiles_n = (g.n + BN - 1) / BN;
+      const int64_t total = (m_lim + BM - 1) / BM * sk_tiles_n * sk_S;
+      // consecutive ranges (the two column halves of a row block, read from the same A rows)
+      // go to workgroups of the SAME XCD, which share an L2: workgroup ids are dealt to the 8
+      // XCDs round-robin
+      unsigned lb = blockIdx.x;
+      if (gridDim.x % 8 == 0) lb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+      sk_it = total * lb / gridDim.x;
+      sk_end = total * (lb + 1) / gridDim.x;
+      if (sk_it >= sk_end) return;
+    } else if (m0 >= m_lim) {
+      return;
+    }
+  } else {
+    if (m0 >= m_lim) return;
+  }
   const int64_t n_lim = prob ? g.n2 : g.n;
   float* const out_p = prob ? g.out2 : g.out;
   const int64_t ld_out_p = prob ? g.ld_out2 : g.ld_out;
@@ -251,25 +407,19 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   };
 
   floatx16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   float csum[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) csum[i] = 0.f;
 
-  TileLoader<A_KC, BM, VEC> la;
-  TileLoader<B_KC, BN, VEC> lb;
+  std::conditional_t<kDual, DualLoader<BM, VEC>, TileLoader<A_KC, BM, VEC>> la;
+  std::conditional_t<kDual, DualLoader<BN, VEC>, TileLoader<B_KC, BN, VEC>> lb;
 
   typedef float f4v __attribute__((ext_vector_type(4)));
   constexpr int NG = BK / 8;
-  // PAR = parity of the step within its segment = register set that holds step k0 + 2*BK... :
-  // step (k0) computes from (as, bs), stores set PAR^1 (step k0+BK) into (as_next, bs_next) and
-  // requests step k0+3*BK into set PAR^1.
-  auto k_step = [&](auto par, int k0, const float* as, const float* bs, float* as_next, float* bs_next) {
+  // PAR = parity of the (unified) step = register set that holds step + 2: the step computes
+  // from (as, bs), stores set PAR^1 (step + 1) into (as_next, bs_next) and requests step + 3
+  // into set PAR^1.
+  auto k_step = [&](auto par, int step, const float* as, const float* bs, float* as_next, float* bs_next) {
     constexpr int PAR = decltype(par)::value;
     float af[NG][TM][4], bf[NG][TN][4];
     auto read_group = [&](int g) {
@@ -315,19 +465,114 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (g == 1) {
-        la.template store<LDA, PAR ^ 1>(k0 + BK, as_next);
-        lb.template store<LDB, PAR ^ 1>(k0 + BK, bs_next);
+        la.template store<LDA, PAR ^ 1>(step + 1, as_next);
+        lb.template store<LDB, PAR ^ 1>(step + 1, bs_next);
         __builtin_amdgcn_sched_barrier(0);
       }
       if (g == 2) {
-        la.template issue<PAR ^ 1>(k0 + 3 * BK);
-        lb.template issue<PAR ^ 1>(k0 + 3 * BK);
+        la.template issue<PAR ^ 1>(step + 3);
+        lb.template issue<PAR ^ 1>(step + 3);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     __syncthreads();
   };
 
+  for (;;) {   // one pass per tile (piece); a single pass unless stream-K
+  if constexpr (kDual) {
+    if (g.streamk) {
+      const int64_t tile = sk_it / sk_S;
+      sk_u0 = static_cast<int>(sk_it - tile * sk_S);
+      const int64_t left = sk_end - sk_it;
+      sk_u1 = left < sk_S - sk_u0 ? sk_u0 + static_cast<int>(left) : sk_S;
+      sk_partial = !(sk_u0 == 0 && sk_u1 == sk_S);
+      m0 = tile / sk_tiles_n * BM;
+      n0 = tile % sk_tiles_n * BN;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if constexpr (kDual) {
+    // contraction range of each segment for this workgroup (split-K: slice blockIdx.z of both).
+    // (g.seg[] is only indexed with constants: a dynamic index makes the compiler copy the
+    // kernel arguments to scratch memory, and scratch traffic counts on vmcnt)
+    auto seg_range = [&](int k_lim, int& kb_out, int& ke_out) {
+      int k_beg = 0, k_end = k_lim;
+      if (g.k_chunk > 0) {
+        k_beg = bz * g.k_chunk;
+        k_end = k_beg + g.k_chunk < k_lim ? k_beg + g.k_chunk : k_lim;
+      }
+      kb_out = k_beg < k_end ? k_beg : 0;
+      ke_out = k_beg < k_end ? k_end : 0;
+    };
+    int kb0, ke0, kb1 = 0, ke1 = 0;
+    int k_lim0 = g.seg[0].k;
+    if (g.k_dev != nullptr) {
+      const int64_t v = *g.k_dev;
+      if (v < k_lim0) k_lim0 = static_cast<int>(v);
+    }
+    seg_range(k_lim0, kb0, ke0);
+    Operand a1 = g.seg[0].a, b1 = g.seg[0].b;
+    if (g.nseg > 1) {
+      seg_range(g.seg[1].k, kb1, ke1);
+      a1 = g.seg[1].a;
+      b1 = g.seg[1].b;
+    }
+    if (g.streamk) {
+      // unified steps [sk_u0, sk_u1) of this tile: the first sk_S0 lie in segment 0
+      const int a_lo = sk_u0 < sk_S0 ? sk_u0 : sk_S0, a_hi = sk_u1 < sk_S0 ? sk_u1 : sk_S0;
+      const int b_lo = (sk_u0 > sk_S0 ? sk_u0 : sk_S0) - sk_S0, b_hi = (sk_u1 > sk_S0 ? sk_u1 : sk_S0) - sk_S0;
+      const int k_lim1 = g.nseg > 1 ? g.seg[1].k : 0;
+      kb0 = a_hi > a_lo ? a_lo * BK : 0;
+      ke0 = a_hi > a_lo ? (a_hi * BK < k_lim0 ? a_hi * BK : k_lim0) : 0;
+      kb1 = b_hi > b_lo ? b_lo * BK : 0;
+      ke1 = b_hi > b_lo ? (b_hi * BK < k_lim1 ? b_hi * BK : k_lim1) : 0;
+    }
+    la.begin(g.seg[0].a, a1, m0, m_lim);
+    lb.begin(g.seg[0].b, b1, n0, n_lim);
+    const int nsteps = la.range(kb0, ke0, kb1, ke1);
+    lb.range(kb0, ke0, kb1, ke1);
+    if (nsteps > 0) {
+      // (the scheduling barriers keep the program order of the loads: vmcnt counts in issue
+      // order, and the loop's waits are derived from the order seen here)
+      la.template issue<0>(0);
+      lb.template issue<0>(0);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template issue<1>(1);   // requests past the last step are clamped and never stored
+      lb.template issue<1>(1);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template store<LDA, 0>(0, As);
+      lb.template store<LDB, 0>(0, Bs);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template issue<0>(2);
+      lb.template issue<0>(2);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+
+      // One K-step = 4 groups of 8 k.  The fragments of group g+2 are read from LDS while group
+      // g multiplies.  Global loads run TWO steps ahead in two register sets (a 128-byte piece
+      // of a gathered feature row is a fresh HBM access every step, and one step of MFMAs does
+      // not cover its latency): step s stores the tile of step s+1 (requested two steps ago,
+      // set (s+1)&1) into the other LDS buffer behind group 1 and requests step s+3 into the
+      // same set behind group 2.  The loop is unrolled by two so the set index is static.
+      // Pairs of steps in a branch-free loop body (any branch inside it gives the structurised
+      // CFG a path on which the younger load set is the one being stored, and every vmcnt in the
+      // loop degrades to a full drain); an odd last step runs from a copy after the loop.  The
+      // step that would be stored past the last one is a clamped load: its LDS image is written
+      // but never read.
+      int st = 0;
+      for (; st + 1 < nsteps; st += 2) {
+        k_step(std::integral_constant<int, 0>{}, st, As, Bs, As + ASZ, Bs + BSZ);
+        k_step(std::integral_constant<int, 1>{}, st + 1, As + ASZ, Bs + BSZ, As, Bs);
+      }
+      if (nsteps & 1) k_step(std::integral_constant<int, 0>{}, st, As, Bs, As + ASZ, Bs + BSZ);
+    }
+  } else {
   for (int s = s_begin; s < s_end; ++s) {
     const Segment& sg = g.seg[s];
     int k_lim = sg.k;
@@ -337,47 +582,14 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
     }
     int k_beg = 0, k_end = k_lim;
     if (g.k_chunk > 0) {
-      k_beg = blockIdx.z * g.k_chunk;
+      k_beg = bz * g.k_chunk;
       k_end = k_beg + g.k_chunk < k_lim ? k_beg + g.k_chunk : k_lim;
     }
     if (k_beg >= k_end) continue;
 
     la.begin(sg.a, m0, m_lim, k_beg, k_end);
     lb.begin(sg.b, n0, n_lim, k_beg, k_end);
-    if constexpr (A_KC && B_KC) {
-      // (the scheduling barriers keep the program order of the loads: vmcnt counts in issue
-      // order, and the loop's waits are derived from the order seen here)
-      la.template issue<0>(k_beg);
-      lb.template issue<0>(k_beg);
-      __builtin_amdgcn_sched_barrier(0);
-      la.template issue<1>(k_beg + BK);   // loads past k_end are clamped and zeroed later
-      lb.template issue<1>(k_beg + BK);
-      __builtin_amdgcn_sched_barrier(0);
-      la.template store<LDA, 0>(k_beg, As);
-      lb.template store<LDB, 0>(k_beg, Bs);
-      __builtin_amdgcn_sched_barrier(0);
-      la.template issue<0>(k_beg + 2 * BK);
-      lb.template issue<0>(k_beg + 2 * BK);
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-
-      // One K-step = 4 groups of 8 k.  The fragments of group g+2 are read from LDS while group
-      // g multiplies.  Global loads run TWO steps ahead in two register sets (a 128-byte piece
-      // of a gathered feature row is a fresh HBM access every step, and one step of MFMAs does
-      // not cover its latency): step k stores the tile of step k+1 (requested two steps ago,
-      // set (k+1)&1) into the other LDS buffer behind group 1 and requests step k+3 into the
-      // same set behind group 2.  The loop is unrolled by two so the set index is static.
-      // pairs of steps in a branch-free loop body (any branch inside it gives the structurised
-      // CFG a path on which the younger load set is the one being stored, and every vmcnt in the
-      // loop degrades to a full drain); an odd last step runs from a copy after the loop
-      const int nsteps = (k_end - k_beg + BK - 1) / BK;
-      int k0 = k_beg;
-      for (int i = 0; i + 1 < nsteps; i += 2, k0 += 2 * BK) {
-        k_step(std::integral_constant<int, 0>{}, k0, As, Bs, As + ASZ, Bs + BSZ);
-        k_step(std::integral_constant<int, 1>{}, k0 + BK, As + ASZ, Bs + BSZ, As, Bs);
-      }
-      if (nsteps & 1) k_step(std::integral_constant<int, 0>{}, k0, As, Bs, As + ASZ, Bs + BSZ);
-    } else {
+    {
       // d-input / d-weight: one register set, request step k+1 before the MFMAs of step k and
       // store it behind them (the deeper pipeline above does not fit the register budget of
       // the k-major fragment reads)
@@ -454,6 +666,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
       }
     }
   }
+  }  // !kDual
 
   if constexpr (kPairN) {
     // The K-loop computed column tiles (j, j+1) interleaved: lane c holds columns 2c and 2c+1
@@ -494,7 +707,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
       const int64_t col = n0 + ncol(j);
       const int64_t row0 = m0 + wm0 + i * 32 + 4 * half;
       float* base = out_p + row0 * ld_out_p + col;
-      if (g.atomic_out) {  // block-uniform
+      if (g.atomic_out || sk_partial) {  // block-uniform
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int r = (e & 3) + 8 * (e >> 2);
@@ -511,7 +724,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
       }
     }
   }
-  if (g.colsum != nullptr && blockIdx.y == 0 && (wave & 1) == 0) {
+  if (g.colsum != nullptr && by_ == 0 && (wave & 1) == 0) {
     // the two lane halves summed disjoint k slots of row (wm0 + i*32 + l31)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -520,6 +733,27 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
       if (half == 0 && row < m_lim) atomicAdd(g.colsum + row, tot);
     }
   }
+  if constexpr (kDual) {
+    if (g.streamk) {
+      sk_it += sk_u1 - sk_u0;
+      if (sk_it < sk_end) continue;
+    }
+  }
+  break;
+  }  // tile pieces
+}
+
+// CUs of the current device (0 if the query fails: callers then keep whole-tile grids)
+int num_cus() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  if (cached[dev] == 0) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    cached[dev] = v;
+  }
+  return cached[dev];
 }
 
 bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -782,6 +1016,30 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
     if (!accum) zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
     SAGE_CHECK_LAUNCH("zero_rows_kernel");
     return launch_gemm<true, true>(g, splits, stream, "gemm_kernel(fwd, split-K)");
+  }
+  // Whole tiles that do not fill the last round of workgroup slots (two resident workgroups per
+  // CU) leave CUs idle while others still hold two tiles — layer 0 on the Reddit shape: 410 tiles
+  // on 512 slots, critical path 2 tile-times for 1.6 of work.  Stream-K: one workgroup per slot,
+  // every one takes the same number of K-steps, partial tiles are added with fp32 atomics into a
+  // zeroed output.
+  const int slots = 2 * num_cus();
+  if ((epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && n > 64 && slots > 0 && tiles > slots / 2 &&
+      tiles * 10 < cdiv(tiles, slots) * slots * 9) {
+    g.streamk = 1;
+    g.atomic_out = accum ? 1 : 0;   // out += product: whole tiles are added too
+    if (!accum) zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
+    SAGE_CHECK_LAUNCH("zero_rows_kernel");
+    int vec = 4;
+    for (int sgi = 0; sgi < g.nseg; ++sgi) {
+      if (g.seg[sgi].a.vec < vec) vec = g.seg[sgi].a.vec;
+      if (g.seg[sgi].b.vec < vec) vec = g.seg[sgi].b.vec;
+    }
+    const dim3 grid(static_cast<unsigned>(slots));
+    if (vec == 4) gemm_kernel<true, true, 64, 128, 4><<<grid, kThreads, 0, stream>>>(g);
+    else if (vec == 2) gemm_kernel<true, true, 64, 128, 2><<<grid, kThreads, 0, stream>>>(g);
+    else gemm_kernel<true, true, 64, 128, 1><<<grid, kThreads, 0, stream>>>(g);
+    SAGE_CHECK_LAUNCH("gemm_kernel(fwd, stream-K)");
+    return SAGE_OK;
   }
   if (accum) g.atomic_out = 1;   // out += product
   return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");

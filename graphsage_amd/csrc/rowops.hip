@@ -33,15 +33,15 @@ __device__ inline float wave_max(float v) {
 // 16-byte vectors (one per lane covers n = 256), twice the bytes per instruction of the scalar form
 template <bool V4>
 __global__ void __launch_bounds__(kBlock)
-l2norm_relu_fwd_kernel(const float* __restrict__ z, int64_t ld_z, int64_t m,
+l2norm_relu_fwd_kernel(float* __restrict__ z, int64_t ld_z, int64_t m,
                        const int64_t* __restrict__ m_dev, int n, float* __restrict__ y,
                        int64_t ld_y, float* __restrict__ h, int64_t ld_h,
-                       float* __restrict__ inv_norm) {
+                       float* __restrict__ inv_norm, int clear_z) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t rows = dev_count(m_dev, m);
   const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
   if (r >= rows) return;
-  const float* zr = z + r * ld_z;
+  float* zr = z + r * ld_z;
   float ss = 0.f;
   if constexpr (V4) {
     for (int f = lane * 4; f < n; f += kWave * 4) {
@@ -66,12 +66,15 @@ l2norm_relu_fwd_kernel(const float* __restrict__ z, int64_t ld_z, int64_t m,
         *reinterpret_cast<float4*>(h + r * ld_h + f) =
             make_float4(v.x > 0.f ? v.x : 0.f, v.y > 0.f ? v.y : 0.f, v.z > 0.f ? v.z : 0.f, v.w > 0.f ? v.w : 0.f);
       }
+      // the producer adds partial sums (stream-K / split-K) into zeros next time
+      if (clear_z) *reinterpret_cast<float4*>(zr + f) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   } else {
     for (int f = lane; f < n; f += kWave) {
       const float v = zr[f] / denom;
       y[r * ld_y + f] = v;
       if (h != nullptr) h[r * ld_h + f] = v > 0.f ? v : 0.f;
+      if (clear_z) zr[f] = 0.f;
     }
   }
 }
@@ -357,22 +360,25 @@ __global__ void bump_step2_kernel(const int64_t* step_in, int64_t* step_out) { *
 
 using namespace sage;
 
-extern "C" int sage_l2norm_relu_fwd(const float* z, sage_i64 ld_z, sage_i64 m,
+extern "C" int sage_l2norm_relu_fwd(float* z, sage_i64 ld_z, sage_i64 m,
                                     const sage_i64* m_dev, int n, float* y, sage_i64 ld_y,
-                                    float* h, sage_i64 ld_h, float* inv_norm, void* stream_) {
+                                    float* h, sage_i64 ld_h, float* inv_norm, int clear_z,
+                                    void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(m >= 0 && n > 0 && ld_z >= n && ld_y >= n && (h == nullptr || ld_h >= n),
                SAGE_EINVAL, "sage_l2norm_relu_fwd: bad shape");
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(z && y, SAGE_EINVAL, "sage_l2norm_relu_fwd: NULL pointer argument");
+  SAGE_REQUIRE(!clear_z || (y != z && h != z), SAGE_EINVAL,
+               "sage_l2norm_relu_fwd: clear_z with an output aliasing z");
   const bool v4 = n % 4 == 0 && ld_z % 4 == 0 && ld_y % 4 == 0 && (h == nullptr || ld_h % 4 == 0) &&
                   vec16(z) && vec16(y) && vec16(h);
   if (v4) {
     l2norm_relu_fwd_kernel<true><<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
-        z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm);
+        z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm, clear_z);
   } else {
     l2norm_relu_fwd_kernel<false><<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
-        z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm);
+        z, ld_z, m, m_dev, n, y, ld_y, h, ld_h, inv_norm, clear_z);
   }
   SAGE_CHECK_LAUNCH("l2norm_relu_fwd_kernel");
   return SAGE_OK;

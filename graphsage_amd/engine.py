@@ -362,13 +362,16 @@ class SageTrainEngine:
                 lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
                                       num_targets_dev=t_dev, out=agg, want_argmax=self.reduce == 'max',
                                       argmax=a.get('argmax'))
-            # supervised step: the logit layer accumulates its split-K partial sums into z, which
-            # the fused loss kernel hands back zeroed (z starts as zeros): no fill kernel
+            # The GEMMs ADD into z (stream-K / split-K partial sums), and every z starts as zeros:
+            # the consumer hands it back zeroed (clear_z of the normalise kernel, of the fused
+            # loss kernel in the supervised step), so there is no fill kernel.  Only the unsup
+            # variants' logit layer has no clearing consumer.
             lib.linear_concat_fwd(agg, layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
                                   m_dev=t_dev, rows2=node_map, out=a['z'],
-                                  accumulate=(i == L - 1 and not self.unsup))
+                                  accumulate=(i < L - 1 or not self.unsup))
             if i < L - 1:
-                lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'])
+                lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'],
+                                    clear_z=True)
             x, node_map = a.get('h'), None
 
     def _forward(self, slot, skip_gather0):

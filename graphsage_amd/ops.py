@@ -510,9 +510,10 @@ def linear_dweight2(dout, a1, dw1, a2, dw2, m=None, m_dev=None, rows1=None, rows
 
 
 # ------------------------------------------------------------------------------- rows
-def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None):
+def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None, clear_z=False):
     """y = normalize(z); h = relu(y) if relu (reference layers/sage.py:131-132,
-    models/graphsage.py:47-48).  Returns (y, h or None, inv_norm)."""
+    models/graphsage.py:47-48).  Returns (y, h or None, inv_norm).  clear_z=True zeroes the
+    consumed rows of z (its producer may then accumulate into it)."""
     lib = _lib.load()
     zp, ld_z = _mat(z, "z")
     m = z.size(0) if m is None else int(m)
@@ -532,7 +533,7 @@ def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None):
     if z.size(0) < m or y.size(0) < m or y.size(1) != n or inv_norm.numel() < m:
         raise RuntimeError("l2norm_relu_fwd: bad buffers")
     rc = lib.sage_l2norm_relu_fwd(zp, ld_z, m, _count(m_dev, "m_dev"), n, yp, ld_y, hp, ld_h,
-                                  _vec(inv_norm, torch.float32, "inv_norm"), _stream())
+                                  _vec(inv_norm, torch.float32, "inv_norm"), int(bool(clear_z)), _stream())
     _lib.check(rc, "sage_l2norm_relu_fwd")
     return y, (h if relu else None), inv_norm
 

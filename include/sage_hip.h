@@ -301,9 +301,12 @@ int sage_lstm_cell0_bwd(const float* gates, sage_i64 ld_gates, const float* none
 /* y = z / max(||z||_2, 1e-12)  (F.normalize(p=2, dim=-1), layers/sage.py:131-132) and,
  * if h != NULL, h = relu(y) (the in-place x.relu_() of models/graphsage.py:47-48).
  * inv_norm[m] = 1 / max(||z||, eps) is kept for the backward.  y may alias z. */
-int sage_l2norm_relu_fwd(const float* z, sage_i64 ld_z, sage_i64 m, const sage_i64* m_dev,
+int sage_l2norm_relu_fwd(float* z, sage_i64 ld_z, sage_i64 m, const sage_i64* m_dev,
                          int n, float* y, sage_i64 ld_y, float* h, sage_i64 ld_h,
-                         float* inv_norm, void* stream);
+                         float* inv_norm,
+                         int clear_z /* 1: z rows are zeroed after use (consume-and-clear: the
+                                        producer may then run with SAGE_EPI_ACCUM); excludes aliasing */,
+                         void* stream);
 /* dz = (g - y * <y, g>) * inv_norm, with g = relu_mask ? dh * [y > 0] : dh.
  * Rows whose norm was clamped by eps (inv_norm == 1e12) get dz = g * inv_norm, the
  * gradient torch's clamp_min gives.  dz may alias dh. */

@@ -33,6 +33,36 @@ def test_linear_concat_fwd(dev, m, n, k1, k2):
     torch.testing.assert_close(out.cpu(), want, rtol=RTOL, atol=ATOL)
 
 
+@pytest.mark.parametrize("m,n,k1,k2,m_frac", [(13100, 256, 602, 602, 1.0), (9000, 200, 100, 0, 1.0),
+                                              (26000, 256, 64, 40, 0.6), (8300, 256, 33, 31, 1.0)])
+def test_linear_concat_fwd_stream_k(dev, m, n, k1, k2, m_frac):
+    """Shapes whose tile count leaves the last round of workgroup slots part-filled take the
+    stream-K schedule (partial tiles combined with atomics): same values as the whole-tile grid,
+    with a row map, a device-side row count, into a zeroed buffer (accumulate) and a dirty one."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m + n + k1)
+    N = 5000
+    a1, w1 = _rand((m, k1), g), _rand((n, k1), g, k1 ** -0.5)
+    want = a1 @ w1.t()
+    a2 = w2 = rows = None
+    if k2:
+        table, w2 = _rand((N, k2), g), _rand((n, k2), g, k2 ** -0.5)
+        rows = torch.randint(0, N, (m,), generator=g)
+        want = want + table[rows] @ w2.t()
+        a2 = table.to(dev)
+    m_live = int(m * m_frac)
+    mdev = torch.tensor([m_live], device=dev) if m_frac < 1.0 else None
+    out = torch.full((m, n), 7.0, device=dev)              # dirty: the library zeroes it itself
+    ops.linear_concat_fwd(a1.to(dev), w1.to(dev), a2, w2.to(dev) if k2 else None,
+                          rows2=rows.to(dev) if k2 else None, m=m, m_dev=mdev, out=out)
+    torch.testing.assert_close(out[:m_live].cpu(), want[:m_live], rtol=RTOL, atol=ATOL)
+    acc = torch.zeros((m, n), device=dev)                  # accumulate into zeros: no fill kernel
+    ops.linear_concat_fwd(a1.to(dev), w1.to(dev), a2, w2.to(dev) if k2 else None,
+                          rows2=rows.to(dev) if k2 else None, m=m, m_dev=mdev, out=acc, accumulate=True)
+    torch.testing.assert_close(acc[:m_live].cpu(), want[:m_live], rtol=RTOL, atol=ATOL)
+    assert bool((acc[m_live:] == 0).all())
+
+
 def test_linear_concat_rowmaps_bias_relu_devcount(dev):
     from graphsage_amd import ops
     g = torch.Generator().manual_seed(0)
@@ -100,6 +130,13 @@ def test_l2norm_relu(dev, m, n, relu):
     h.backward(dh)
     dz = ops.l2norm_relu_bwd(dh.to(dev), yk, inv, relu)
     torch.testing.assert_close(dz[1:].cpu(), zt.grad[1:], rtol=1e-4, atol=1e-5)
+    # consume-and-clear: same outputs, z handed back zeroed; aliasing outputs are rejected
+    zd = z.to(dev)
+    yk2, hk2, _ = ops.l2norm_relu_fwd(zd, relu, clear_z=True)
+    assert torch.equal(yk2, yk) and (not relu or torch.equal(hk2, hk))
+    assert bool((zd == 0).all())
+    with pytest.raises(RuntimeError):
+        ops.l2norm_relu_fwd(zd, relu, y=zd, clear_z=True)
 
 
 def test_softmax_xent_and_adam(dev):
