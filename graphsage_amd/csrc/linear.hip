@@ -337,11 +337,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   constexpr int TM = BM / 64, TN = BN / 64;
   // n-contiguous B with an even number of column tiles per wave: the tiles are interleaved in
   // pairs so that one 8-byte LDS read serves two MFMAs (see the K-loop); ncol() is the map
-#ifdef SAGE_NO_PAIRN
-  constexpr bool kPairN = false;
-#else
   constexpr bool kPairN = !B_KC && (TN % 2 == 0);
-#endif
   // row stride and size of one LDS buffer per operand: [BM][BK+4] (k contiguous) or [BK][BM+4]
   constexpr int LDA = A_KC ? BK + 4 : BM + 4;
   constexpr int LDB = B_KC ? BK + 4 : BN + 4;
