@@ -129,6 +129,45 @@ def test_train_step_gradients_match_oracle(dev):
             torch.testing.assert_close(m.lin_r.weight.grad.cpu(), p["lin_r"].grad, rtol=1e-3, atol=1e-5)
 
 
+def test_ppi_shaped_multilabel_step_matches_oracle(dev):
+    """BASELINE.json configs[1]: PPI-shaped graph (F=50, 121 sigmoid labels), GraphSAGE-mean
+    602->... replaced by 50->256->121, fan-out 25/10, BCEWithLogitsLoss on the seed rows
+    (examples/ppi_graphsage_supervised.py:30): loss and weight gradients of the sampled step, and
+    the reference's own PPI-supervised form — the FULL graph through SAGE.forward, no sampler
+    (trainers/graph_level_graphsage_trainers.py:34) — against the oracle."""
+    from graphsage_amd.datasets import PPI
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    data = PPI(split='val')[0]
+    assert data.x.size(1) == 50 and data.y.shape == (data.num_nodes, 121)
+    B = 512
+    loader = UniformLoader(data, num_neighbors=[25, 10], batch_size=B, seed=5)
+    layers = make_layers([50, 256, 121], "mean", 6)
+    model = GraphSAGE(50, 256, "mean", 2, 121).to(dev)
+    load_layers(model, layers)
+    batch = next(iter(loader))
+    node, ei = batch.n_id.cpu(), batch.edge_index.cpu()
+    assert torch.equal(batch.y.cpu(), data.y[node])
+    ref_layers = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
+    out_ref = sage_ref.graphsage_forward(data.x[node], ei, ref_layers, "mean")[:B]
+    loss_ref = F.binary_cross_entropy_with_logits(out_ref, data.y[node[:B]])
+    loss_ref.backward()
+    y_hat = model(batch.x, batch.edge_index)[:B]
+    loss = torch.nn.BCEWithLogitsLoss()(y_hat, batch.y[:B])
+    loss.backward()
+    torch.testing.assert_close(y_hat.detach().cpu(), out_ref.detach(), rtol=1e-4, atol=ATOL)
+    torch.testing.assert_close(loss.detach().cpu(), loss_ref.detach(), rtol=1e-5, atol=1e-6)
+    for m, p in zip(model.layers, ref_layers):
+        torch.testing.assert_close(m.lin_l.weight.grad.cpu(), p["lin_l"].grad, rtol=1e-3, atol=1e-6)
+        torch.testing.assert_close(m.lin_r.weight.grad.cpu(), p["lin_r"].grad, rtol=1e-3, atol=1e-6)
+    # full graph, edge list in its stored (unsorted) order
+    with torch.no_grad():
+        full = model(data.x.to(dev), data.edge_index.to(dev))
+        want = sage_ref.graphsage_forward(data.x, data.edge_index, layers, "mean")
+    assert full.shape == (data.num_nodes, 121)
+    torch.testing.assert_close(full.cpu(), want, rtol=1e-4, atol=ATOL)
+
+
 def test_lstm_aggregator_matches_oracle(dev):
     """a-7: parity unpinned against the reference (its lstm code is disabled as broken); the
     kernels are checked against the oracle's well-defined restatement."""
