@@ -28,6 +28,8 @@ SHAPES = {
     # name: (num_nodes, num_edges, num_features, num_classes, num_train)
     "reddit": (232965, 114615892, 602, 41, 153431),
     "reddit-small": (23296, 4000000, 602, 41, 15343),   # for quick functional runs only
+    # BASELINE.json configs[4] (ogbn-products scale; use with --variant unsup): informational
+    "products": (2400000, 62000000, 100, 47, 196615),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -58,12 +60,14 @@ def parse():
                     help="record the probe's events around the gather launch instead of attaching them to it")
     ap.add_argument("--overlap-gather", action="store_true",
                     help="run the layer-0 gather of batch s+1 on the side stream during batch s")
-    ap.add_argument("--variant", default="fig2a", choices=["fig2a", "trainer", "trainer-module"],
+    ap.add_argument("--variant", default="fig2a", choices=["fig2a", "trainer", "trainer-module", "unsup"],
                     help="fig2a: the benchmarked step (supervised term only). trainer: the reference "
                          "trainers' step (node_level_graphsage_trainers.py:34-46: + unsupervised term = two "
                          "more forwards on positive / negative nodes) on the static-shape engine; "
                          "trainer-module: the same through the module path (autograd Functions).  Both "
-                         "are reported separately, never as the headline")
+                         "are reported separately, never as the headline.  unsup: the unsupervised "
+                         "trainer's step (:104-117), loss = the random-walk term alone, embedding width = "
+                         "--hidden (BASELINE.json configs[4] with --workload products)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from HIP graphs instead of launching every kernel eagerly "
                          "(same arithmetic; measured 2-3 %% slower than eager on MI355X / ROCm 7.2)")
@@ -196,6 +200,8 @@ def main():
     data.edge_index = None                                          # CSC is resident; free the COO
     torch.cuda.empty_cache()
     torch.manual_seed(0)
+    if args.variant == "unsup":
+        C = args.hidden              # the unsupervised runners emit embeddings, not class logits
     model = GraphSAGE(Fdim, args.hidden, args.aggregator, len(K), C).to(dev)
     init_layers = [{"lin_l": m.lin_l.weight.detach().cpu().clone(), "lin_r": m.lin_r.weight.detach().cpu().clone()}
                    for m in model.layers]
@@ -205,7 +211,7 @@ def main():
         return trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank)
     engine = SageTrainEngine(model, sampler, feats, labels, B, lr=args.lr, world_size=world, process_group=pg,
                              overlap_gather=args.overlap_gather, group=args.group,
-                             unsup=(args.variant == "trainer"))
+                             unsup={"trainer": True, "unsup": "only"}.get(args.variant, False))
 
     # seeds: first n_train ids of randperm(N, seed 0); rank r takes the strided shard r::world
     gen = torch.Generator().manual_seed(0)
@@ -355,7 +361,7 @@ def main():
                        "value": round(B * nv / tv, 1), "unit": "seed nodes/s", "steps": nv}
             del eng2, model2
         cpu = None
-        if world == 1 and args.cpu_steps > 0:
+        if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a":   # the oracle times fig2a's step
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
             colptr, row = graph.colptr.cpu().numpy(), graph.row.cpu().numpy()
             seeds_list = [train[i * B:(i + 1) * B].numpy() for i in range(args.cpu_steps + 1)]
@@ -371,8 +377,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic: N={N} E={E} F={Fdim} C={C}, "
                                    f"B={B}/GPU, fan-out {K}, hidden {args.hidden}, aggregator {args.aggregator}, "
-                                   f"Adam lr {args.lr}, " + ("fig2a step (supervised term only)" if args.variant == "fig2a" else
-                                                             "TRAINER step (supervised + unsupervised term, 3 forwards)"),
+                                   f"Adam lr {args.lr}, " + {"fig2a": "fig2a step (supervised term only)",
+                                                       "unsup": "UNSUPERVISED trainer step (random-walk loss, 3 forwards)"}.get(
+                                       args.variant, "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},
             "roofline": roofline, "cpu_baseline": cpu, "variant_overlap_gather": variant,
             "final_loss": round(loss, 5), "setup_s": round(setup_s, 1), "settle_steps": base,

@@ -142,7 +142,10 @@ class SageTrainEngine:
         # the unsupervised term — two more forwards over the SAME sampled edges with the features of
         # positive / negative nodes in place of the batch's (trainers/base_trainers.py:170-181) —
         # so every activation exists three times (variant 0 = batch, 1 = positive, 2 = negative)
+        # unsup='only': the unsupervised trainer's step (node_level_graphsage_trainers.py:104-117):
+        # the same three forwards, loss = the unsupervised term alone (BASELINE.json configs[4])
         self.unsup = bool(unsup)
+        self.unsup_only = unsup == 'only'
         nvar = 3 if self.unsup else 1
 
         def make_act():
@@ -389,10 +392,16 @@ class SageTrainEngine:
             lib.l2norm_relu_fwd(last['z'], False, m=B, y=last['y'], inv_norm=last['inv'])
         l0, l1, l2 = (self.acts[v][-1] for v in range(3))
         # loss = CE(out, y) + unsup(out, pos_out, neg_out)   (node_level_graphsage_trainers.py:41)
-        lib.softmax_xent(l0['y'], self.labels, label_rows=buf.node, m=B, loss=self.loss_sup, dlogits=l0['dy'],
-                         checked=True)
-        lib.unsup_loss(l0['y'], l1['y'], l2['y'], l0['dy'], l1['dy'], l2['dy'], self.row_loss, self.loss_unsup, m=B)
-        _lib.tape_py(lambda: torch.add(self.loss_sup, self.loss_unsup, out=self.loss))
+        if self.unsup_only:
+            dy0 = l0['dy'][:B]
+            _lib.tape_py(dy0.zero_)               # sage_unsup_loss ADDS the batch rows' gradient
+            lib.unsup_loss(l0['y'], l1['y'], l2['y'], l0['dy'], l1['dy'], l2['dy'], self.row_loss, self.loss, m=B)
+        else:
+            lib.softmax_xent(l0['y'], self.labels, label_rows=buf.node, m=B, loss=self.loss_sup, dlogits=l0['dy'],
+                             checked=True)
+            lib.unsup_loss(l0['y'], l1['y'], l2['y'], l0['dy'], l1['dy'], l2['dy'], self.row_loss, self.loss_unsup,
+                           m=B)
+            _lib.tape_py(lambda: torch.add(self.loss_sup, self.loss_unsup, out=self.loss))
         for v in range(3):
             last = self.acts[v][-1]
             lib.l2norm_relu_bwd(last['dy'], last['y'], last['inv'], False, m=B, dz=last['dz'])

@@ -27,6 +27,19 @@ def _micro_f1(y_hat, y):
     return acc
 
 
+def _engine_for(trainer, unsup):
+    """Static-shape engine over the trainer's model / optimizer settings / train loader."""
+    from ..engine import SageTrainEngine
+    if not isinstance(trainer.optimizer, torch.optim.Adam):
+        raise RuntimeError("the engine implements Adam")
+    g = trainer.optimizer.param_groups[0]
+    sampler = trainer.train_loader.neighbor_sampler
+    graph = sampler.graph
+    return SageTrainEngine(trainer.model, sampler, graph.features(trainer.data), graph.labels(trainer.data),
+                           trainer.train_loader.batch_size, lr=g['lr'], betas=g['betas'], eps=g['eps'],
+                           weight_decay=g['weight_decay'], unsup=unsup)
+
+
 class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer):
     def __init__(self, data, loader, *args, supervised_only=False, use_engine=None, **kwargs):
         super().__init__(*args, **kwargs)
@@ -44,15 +57,7 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
             self.engine = self._make_engine()
 
     def _make_engine(self):
-        from ..engine import SageTrainEngine
-        if not isinstance(self.optimizer, torch.optim.Adam):
-            raise RuntimeError("the engine implements Adam")
-        g = self.optimizer.param_groups[0]
-        sampler = self.train_loader.neighbor_sampler
-        graph = sampler.graph
-        return SageTrainEngine(self.model, sampler, graph.features(self.data), graph.labels(self.data),
-                               self.train_loader.batch_size, lr=g['lr'], betas=g['betas'], eps=g['eps'],
-                               weight_decay=g['weight_decay'], unsup=not self.supervised_only)
+        return _engine_for(self, unsup=not self.supervised_only)
 
     def train(self, epoch):
         self.model.train()
@@ -92,7 +97,7 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
 
 
 class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
-    def __init__(self, data, loader, *args, **kwargs):
+    def __init__(self, data, loader, *args, use_engine=False, **kwargs):
         super().__init__(*args, **kwargs)
         self.data = data
         mk = lambda mask: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
@@ -100,9 +105,14 @@ class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
         self.train_loader = mk(data.train_mask)
         self.val_loader = mk(data.val_mask)
         self.test_loader = mk(data.test_mask)
+        # use_engine: the epoch runs on the static-shape engine (loss = the unsupervised term
+        # alone, three forwards per batch; mean / sum / max models with Adam)
+        self.engine = _engine_for(self, unsup='only') if use_engine else None
 
     def train(self, epoch):
         self.model.train()
+        if self.engine is not None:
+            return self.engine.train_epoch(self.train_loader._idx_dev, epoch=epoch)
         total = torch.zeros((), device=self.device)
         count = 0
         for batch in self.train_loader:

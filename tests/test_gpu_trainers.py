@@ -136,7 +136,8 @@ def test_supervised_trainer_runs_and_learns(dev, supervised_only, use_engine):
     assert len(tr.results) == 3
 
 
-def test_unsupervised_trainer_runs(dev):
+@pytest.mark.parametrize("use_engine", [False, True])
+def test_unsupervised_trainer_runs(dev, use_engine):
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import UniformLoader
     from graphsage_amd.trainers import UnsupervisedGraphSageTrainerForNodeLevelTask, dataloader_kwargs
@@ -149,7 +150,8 @@ def test_unsupervised_trainer_runs(dev):
     dataloader_kwargs['batch_size'] = 128
     try:
         tr = UnsupervisedGraphSageTrainerForNodeLevelTask(data, UniformLoader, model=model, optimizer=opt,
-                                                          num_epochs=2, device=dev, k1=6, k2=4)
+                                                          num_epochs=2, device=dev, k1=6, k2=4,
+                                                          use_engine=use_engine)
     finally:
         dataloader_kwargs.update(old)
     best = tr.run(verbose=False)
@@ -178,10 +180,12 @@ def test_fig2b_harness(dev):
         assert out['test_time'] > 0 and out['test_f1'] > 0.5
 
 
-def test_engine_trainer_step_with_unsup_term_matches_oracle(dev):
+@pytest.mark.parametrize("unsup", [True, "only"])
+def test_engine_trainer_step_with_unsup_term_matches_oracle(dev, unsup):
     """f-2 on the engine: loss = CE + unsupervised term (three forwards over one sampled batch,
-    trainers/node_level_graphsage_trainers.py:41 + base_trainers.py:170-181), gradients and the
-    Adam step against the CPU oracle.  Positive / negative ids are bit-exact restatements."""
+    trainers/node_level_graphsage_trainers.py:41 + base_trainers.py:170-181) or the unsupervised
+    term alone (:104-117; BASELINE.json configs[4]), gradients and the Adam step against the CPU
+    oracle.  Positive / negative ids are bit-exact restatements."""
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import NeighborSampler
@@ -193,7 +197,7 @@ def test_engine_trainer_step_with_unsup_term_matches_oracle(dev):
     load_layers(model, layers)
     graph = device_graph(data)
     engine = SageTrainEngine(model, NeighborSampler(data, fan, seed=seed), graph.features(data),
-                             graph.labels(data), B, lr=lr, unsup=True, keep_grads=True)
+                             graph.labels(data), B, lr=lr, unsup=unsup, keep_grads=True)
     c0, r0, _ = csc.to_csc(data.edge_index.numpy(), data.num_nodes)
     train = data.train_mask.nonzero().view(-1)
     params = [{k: v.clone() for k, v in p.items()} for p in layers]
@@ -210,7 +214,9 @@ def test_engine_trainer_step_with_unsup_term_matches_oracle(dev):
         leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
         ei = torch.from_numpy(np.stack([src, dst]))
         outs = [sage_ref.graphsage_forward(data.x[torch.from_numpy(ids)], ei, leaf)[:B] for ids in (node, pos, neg)]
-        want = F.cross_entropy(outs[0], data.y[torch.from_numpy(node[:B])]) + sage_ref.unsup_loss(*outs)
+        want = sage_ref.unsup_loss(*outs)
+        if unsup is True:
+            want = want + F.cross_entropy(outs[0], data.y[torch.from_numpy(node[:B])])
         want.backward()
         torch.testing.assert_close(loss.cpu(), want.detach().view(1), rtol=1e-5, atol=1e-6)
         for m, lf in zip(model.layers, leaf):
