@@ -56,3 +56,26 @@ def all_reduce_flat(flat_grad, group=None, async_op=False):
         work = dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         return work if async_op else flat_grad
     return None if async_op else flat_grad
+
+
+def all_reduce_gradients(model, group=None):
+    """Module path under data parallelism (any aggregator, any loss): average the gradients of
+    `model` over ranks with ONE all-reduce of a flat buffer, in place — call it between
+    loss.backward() and optimizer.step().  Parameters without a gradient on this rank count as
+    zeros, so every rank reduces the same layout.  No-op outside a process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return
+    params = [p for p in model.parameters() if p.requires_grad]
+    if not params:
+        return
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    all_reduce_flat(flat, group)
+    flat.div_(dist.get_world_size(group))
+    off = 0
+    for p in params:
+        n = p.numel()
+        if p.grad is None:
+            p.grad = flat[off:off + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n

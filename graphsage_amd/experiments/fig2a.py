@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from .. import settings
 from ..datasets import Planetoid, Reddit
+from ..dist import all_reduce_gradients
 from ..models import GraphSAGE
 from ..samplers import UniformLoader
 
@@ -63,6 +64,7 @@ def train(epoch, model, optimizer, train_loader, engine=None):
         y_hat = model(batch.x.to(dev), batch.edge_index.to(dev))[:batch.batch_size]
         loss = F.cross_entropy(y_hat, y)
         loss.backward()
+        all_reduce_gradients(model)      # data parallel: average over ranks (no-op otherwise)
         optimizer.step()
         total += loss.detach() * batch.batch_size
         examples += batch.batch_size

@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import settings
+from ..dist import all_reduce_gradients
 from .base_trainers import GraphSageBaseTrainer, SupervisedGraphSageBaseTrainer, dataloader_kwargs
 
 
@@ -25,6 +26,21 @@ def _micro_f1(y_hat, y):
     """accuracy == micro-averaged F1 for single-label multi-class predictions."""
     acc = (y_hat == y).sum().float() / max(int(y.numel()), 1)
     return acc
+
+
+def _dp_shard():
+    """Loader kwargs that shard the seeds over the ranks of an initialised process group (one
+    process per GPU; evaluation loaders stay whole on every rank)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return {'rank': dist.get_rank(), 'world_size': dist.get_world_size()}
+    return {}
+
+
+def _dp_engine():
+    import torch.distributed as dist
+    kw = _dp_shard()
+    return {'world_size': kw['world_size'], 'process_group': dist.group.WORLD} if kw else {}
 
 
 def _engine_for(trainer, unsup):
@@ -37,7 +53,7 @@ def _engine_for(trainer, unsup):
     graph = sampler.graph
     return SageTrainEngine(trainer.model, sampler, graph.features(trainer.data), graph.labels(trainer.data),
                            trainer.train_loader.batch_size, lr=g['lr'], betas=g['betas'], eps=g['eps'],
-                           weight_decay=g['weight_decay'], unsup=unsup)
+                           weight_decay=g['weight_decay'], unsup=unsup, **_dp_engine())
 
 
 class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer):
@@ -45,9 +61,9 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
         super().__init__(*args, **kwargs)
         self.data = data
         self.supervised_only = supervised_only
-        mk = lambda mask: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
-                                 **dataloader_kwargs)
-        self.train_loader = mk(data.train_mask)
+        mk = lambda mask, **kw: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
+                                       **dataloader_kwargs, **kw)
+        self.train_loader = mk(data.train_mask, **_dp_shard())   # training seeds sharded over ranks
         self.val_loader = mk(data.val_mask)
         self.test_loader = mk(data.test_mask)
         self.engine = None
@@ -63,7 +79,7 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
         self.model.train()
         if self.engine is not None:
             seeds = self.train_loader._idx_dev
-            return self.engine.train_epoch(seeds, epoch=epoch)
+            return self.engine.train_epoch(seeds, epoch=epoch, rank=_dp_shard().get('rank', 0))
         total = torch.zeros((), device=self.device)
         count = 0
         for batch in self.train_loader:
@@ -75,6 +91,7 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
             if not self.supervised_only:
                 loss = loss + self.unsup_loss_fn(y_hat, batch, self.data)
             loss.backward()
+            all_reduce_gradients(self.model)      # data parallel: average over ranks (no-op otherwise)
             self.optimizer.step()
             total += loss.detach() * batch.batch_size
             count += batch.batch_size
@@ -100,9 +117,9 @@ class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
     def __init__(self, data, loader, *args, use_engine=False, **kwargs):
         super().__init__(*args, **kwargs)
         self.data = data
-        mk = lambda mask: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
-                                 **dataloader_kwargs)
-        self.train_loader = mk(data.train_mask)
+        mk = lambda mask, **kw: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
+                                       **dataloader_kwargs, **kw)
+        self.train_loader = mk(data.train_mask, **_dp_shard())   # training seeds sharded over ranks
         self.val_loader = mk(data.val_mask)
         self.test_loader = mk(data.test_mask)
         # use_engine: the epoch runs on the static-shape engine (loss = the unsupervised term
@@ -112,7 +129,7 @@ class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
     def train(self, epoch):
         self.model.train()
         if self.engine is not None:
-            return self.engine.train_epoch(self.train_loader._idx_dev, epoch=epoch)
+            return self.engine.train_epoch(self.train_loader._idx_dev, epoch=epoch, rank=_dp_shard().get('rank', 0))
         total = torch.zeros((), device=self.device)
         count = 0
         for batch in self.train_loader:
@@ -121,6 +138,7 @@ class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
             out = self.model(batch.x, batch.edge_index)[:batch.batch_size]
             loss = self.unsup_loss_fn(out, batch, self.data)
             loss.backward()
+            all_reduce_gradients(self.model)      # data parallel: average over ranks (no-op otherwise)
             self.optimizer.step()
             total += loss.detach() * out.size(0)
             count += batch.batch_size

@@ -27,7 +27,17 @@ def _worker(rank, world, port, out):
         p, m, v = sage_ref.adam_ref(p, grad / world, m, v, step, 1e-2)
     gathered = [torch.zeros(50) for _ in range(world)]
     dist.all_gather(gathered, p)
-    out[rank] = (mine.tolist(), counters, [t.tolist() for t in gathered])
+    # module-path helper: gradients averaged over ranks (one parameter has no gradient on rank 1)
+    from graphsage_amd.dist import all_reduce_gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    x = torch.full((5, 4), float(rank + 1))
+    h = net[0](x)
+    (net[1](h).sum() if rank == 0 else h.sum()).backward()
+    local = [None if q.grad is None else q.grad.clone() for q in net.parameters()]
+    all_reduce_gradients(net)
+    grads = [q.grad.clone() for q in net.parameters()]
+    out[rank] = (mine.tolist(), counters, [t.tolist() for t in gathered], local, grads)
     dist.destroy_process_group()
 
 
@@ -41,3 +51,7 @@ def test_gloo_world2():
     assert len(a[0]) == len(b[0]) == 500 and not set(a[0]) & set(b[0])     # equal, disjoint shards
     assert not set(a[1]) & set(b[1]) and len(set(a[1])) == 14                 # distinct Philox streams
     assert a[2][0] == a[2][1] == b[2][0] == b[2][1]                           # replicas bit-identical
+    for la, lb, ga, gb in zip(a[3], b[3], a[4], b[4]):
+        lb = torch.zeros_like(la) if lb is None else lb
+        assert torch.equal(ga, gb)
+        torch.testing.assert_close(ga, (la + lb) / 2)

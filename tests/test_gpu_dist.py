@@ -105,3 +105,48 @@ def test_engine_data_parallel_two_ranks(dev):
         ops.adam_step(eng.flat, eng.grad, eng.exp_avg, eng.exp_avg_sq, eng._steps[:1], 1e-2,
                       grad_scale=1.0 / world)
     torch.testing.assert_close(eng.flat.cpu(), flat0, rtol=1e-4, atol=1e-6)
+
+
+def _trainer_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn.functional as F
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    from graphsage_amd.trainers import SupervisedGraphSageTrainerForNodeLevelTask, dataloader_kwargs
+    dev = torch.device("cuda:0")
+    data = planted_partition(1500, 30000, 24, 5, seed=8)
+    n = data.num_nodes
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    for name, sl in (("train_mask", perm[:600]), ("val_mask", perm[600:900]), ("test_mask", perm[900:])):
+        m = torch.zeros(n, dtype=torch.bool)
+        m[sl] = True
+        setattr(data, name, m)
+    torch.manual_seed(3)
+    model = GraphSAGE(24, 16, "max_pool", 2, 5).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    dataloader_kwargs['batch_size'] = 100
+    tr = SupervisedGraphSageTrainerForNodeLevelTask(data, UniformLoader, supervised_only=True, use_engine=False,
+                                                    loss_fn=F.cross_entropy, model=model, optimizer=opt,
+                                                    num_epochs=2, device=dev, k1=5, k2=3)
+    best = tr.run(verbose=False)
+    seeds = tr.train_loader._idx_dev.cpu().tolist()
+    out[rank] = (torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()]), seeds, best['test_f1'])
+    dist.destroy_process_group()
+
+
+def test_module_path_trainer_data_parallel_two_ranks(dev):
+    """Any aggregator under data parallelism goes through the module path: seeds sharded over the
+    ranks, gradients averaged with one flat all-reduce (graphsage_amd.dist.all_reduce_gradients)
+    — max_pool model, two ranks on the one GPU: replicas stay bit-identical and learn."""
+    world = 2
+    out = mp.Manager().dict()
+    port = 29100 + (os.getpid() % 150)
+    mp.spawn(_trainer_worker, args=(world, port, out), nprocs=world, join=True)
+    w0, s0, f0 = out[0]
+    w1, s1, f1 = out[1]
+    assert torch.equal(w0, w1)
+    assert len(s0) == len(s1) == 300 and not set(s0) & set(s1)
+    assert f0 == f1 and f0 > 0.5
