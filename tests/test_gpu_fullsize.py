@@ -1,0 +1,145 @@
+"""GPU checks at BASELINE.json's FULL size (Reddit shape: N = 232,965, E = 114,615,892, F = 602,
+B = 512, fan-out 25/10), where the CPU oracle would take minutes: size-independent properties
+(a permutation is a permutation, sortedness, per-target counts, checksums) and independent
+recomputation with plain torch ops on the device (index_select / index_add_ / matmul — not the
+library's kernels).  The small-size tests hold the bit-exact / oracle comparisons."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+N, E, FEAT, C, B, FAN = 232965, 114615892, 602, 41, 512, [25, 10]
+
+
+@pytest.fixture(scope="module")
+def reddit(dev):
+    from graphsage_amd.datasets import reddit_like_device
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = reddit_like_device(N, E, FEAT, C, seed=0, device=dev)
+    graph = device_graph(data)
+    yield data, graph
+    del data, graph
+    torch.cuda.empty_cache()
+
+
+def test_csc_build_full_size(reddit, dev):
+    """to_csc (samplers/uniform_loader.py:32) on 114.6 M edges: colptr is the histogram's scan,
+    perm is a permutation that sorts the edges by (col, row), row = edge_index[0][perm]."""
+    data, graph = reddit
+    ei = data.edge_index
+    colptr, row, perm = graph.colptr, graph.row, graph.perm
+    assert colptr.numel() == N + 1 and int(colptr[0]) == 0 and int(colptr[-1]) == E
+    assert row.numel() == E and perm.numel() == E
+    assert torch.equal(colptr[1:] - colptr[:-1], torch.bincount(ei[1], minlength=N))
+    seen = torch.zeros(E, dtype=torch.uint8, device=dev)
+    seen[perm] = 1
+    assert int(seen.sum()) == E                                       # every edge exactly once
+    del seen
+    assert torch.equal(ei[0][perm], row)
+    key = ei[1][perm] * N + row                                       # sorted by column, then by row
+    assert bool((key[1:] >= key[:-1]).all())
+    del key
+    # stable: equal keys keep their input order
+    same = (ei[1][perm][1:] == ei[1][perm][:-1]) & (row[1:] == row[:-1])
+    assert bool((perm[1:][same] > perm[:-1][same]).all())
+
+
+def _sample(graph, dev, counter=3):
+    from graphsage_amd import ops
+    seeds = torch.randperm(N, generator=torch.Generator().manual_seed(1))[:B].to(dev)
+    buf = ops.SampleBuffers(N, B * (1 + 25 + 250), B * (25 + 250), dev)
+    table = ops.new_relabel_table(N, dev)
+    ops.sample_fanout(graph.colptr, graph.row, seeds, FAN, 0, counter, table, 1, buf)
+    return seeds, buf
+
+
+def test_sampler_full_size_invariants(reddit, dev):
+    data, graph = reddit
+    colptr, row = graph.colptr, graph.row
+    seeds, buf = _sample(graph, dev)
+    st = buf.state.tolist()
+    nn, ne = st[0], st[1]
+    assert st[4] == 0 and nn > 50000 and ne > 100000                 # Reddit degrees: nearly full fan-out
+    node, src, dst, eid = buf.node[:nn], buf.src[:ne], buf.dst[:ne], buf.eid[:ne]
+    seg = buf.seg_ptr[:nn + 1]
+    assert torch.equal(node[:B], seeds)
+    assert node.unique().numel() == nn
+    assert torch.equal(row[eid], node[src])
+    owner = torch.searchsorted(colptr, eid, right=True) - 1
+    assert torch.equal(owner, node[dst])
+    deg = (colptr[1:] - colptr[:-1])[node]
+    k = torch.where(torch.arange(nn, device=dev) < B, 25, 10)
+    want = torch.minimum(deg, k)
+    want[st[9]:] = 0
+    assert torch.equal(seg[1:] - seg[:-1], want)
+    assert bool((dst[1:] >= dst[:-1]).all())
+    assert (dst * (E + 1) + eid).unique().numel() == ne               # without replacement
+    # the same counter gives the same batch, another counter another one
+    _, again = _sample(graph, dev)
+    assert torch.equal(again.node[:nn], node) and torch.equal(again.eid[:ne], eid)
+    _, other = _sample(graph, dev, counter=4)
+    assert not torch.equal(other.eid[:ne], eid)
+
+
+def test_gather_mean_full_size_against_torch_ops(reddit, dev):
+    """Layer-0 fused gather + mean over the sampled batch, read through node_map from the padded
+    table, against index_select + index_add_ on the device (fp32; differs by summation order
+    only: rtol 1e-5, atol 1e-6 as in test_gpu_gather.py)."""
+    from graphsage_amd import ops
+    data, graph = reddit
+    feats = graph.features(data)
+    assert feats.stride(0) == 608                                     # 16-byte aligned rows
+    _, buf = _sample(graph, dev)
+    st = buf.state.tolist()
+    nn, ne, t1 = st[0], st[1], st[9]
+    out, _ = ops.gather_reduce_fwd(feats, buf.seg_ptr, buf.src, t1, "mean", node_map=buf.node)
+    src, dst = buf.src[:ne], buf.dst[:ne]
+    ref = torch.zeros(t1, FEAT, device=dev).index_add_(0, dst, data.x[buf.node[:nn][src]])
+    cnt = (buf.seg_ptr[1:t1 + 1] - buf.seg_ptr[:t1]).clamp(min=1).unsqueeze(1)
+    torch.testing.assert_close(out, ref / cnt, rtol=1e-5, atol=1e-6)
+    # checksum of checksums: the column sums of (mean * count) equal those of all gathered rows
+    torch.testing.assert_close((out.double() * cnt).sum(0), data.x[buf.node[:nn][src]].double().sum(0),
+                               rtol=1e-6, atol=1e-3)
+
+
+def test_engine_step_full_size_matches_module_path(reddit, dev):
+    """One fig2a step on the static-shape engine (stream-K forward, batched weight gradients,
+    fused loss) against the module path (autograd Functions) and against torch's own matmul for
+    the logits: same batch, same weights."""
+    import copy
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    data, graph = reddit
+    torch.manual_seed(0)
+    model = GraphSAGE(FEAT, 256, "mean", 2, C).to(dev)
+    ref_model = copy.deepcopy(model)
+    sampler = NeighborSampler.from_graph(graph, FAN, seed=0)
+    engine = SageTrainEngine(model, sampler, graph.features(data), graph.labels(data), B, lr=1e-3,
+                             keep_grads=True)
+    seeds = torch.randperm(N, generator=torch.Generator().manual_seed(2))[:B].to(dev)
+    before = [p.detach().clone() for p in model.parameters()]
+    loss = engine.step(seeds, counter=11)
+    buf = engine.buf
+    st = buf.state.tolist()
+    nn, ne = st[0], st[1]
+    node, ei = buf.node[:nn], torch.stack([buf.src[:ne], buf.dst[:ne]])
+    # module path on the same sampled batch
+    ref_model.prune_to_seeds = True
+    y_hat = ref_model(data.x[node], ei)[:B]
+    ref_loss = F.cross_entropy(y_hat, data.y[seeds])
+    ref_loss.backward()
+    torch.testing.assert_close(loss.view(()), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+    for p, q in zip(model.parameters(), ref_model.parameters()):
+        torch.testing.assert_close(engine.gviews[p], q.grad, rtol=1e-3, atol=1e-7)
+    # plain torch ops, no library kernel: mean aggregation by index_add_, F.linear, F.normalize
+    x = data.x[node]
+    h = x
+    for i, (wl, wr) in enumerate(zip(before[0::2], before[1::2])):
+        agg = torch.zeros_like(h).index_add_(0, ei[1], h[ei[0]])
+        cnt = torch.bincount(ei[1], minlength=nn).clamp(min=1).unsqueeze(1)
+        h = F.normalize(F.linear(agg / cnt, wl) + F.linear(h, wr), p=2.0, dim=-1)
+        if i == 0:
+            h = h.relu()
+    plain = F.cross_entropy(h[:B], data.y[seeds])
+    torch.testing.assert_close(loss.view(()), plain, rtol=1e-4, atol=1e-5)
