@@ -64,6 +64,39 @@ def model_case(case, aggregator, dims, feat_seed, layer_seed, lr=1e-2):
     return out
 
 
+def unsup_case(case, dims, feat_seed, layer_seed, lr=1e-2):
+    """The trainers' step on the golden batch (mean aggregator): positive / negative node ids
+    (samplers/utils.py:7-37 restated with the build's Philox counters), the unsupervised loss
+    alone and supervised + unsupervised, with their weight gradients."""
+    n = int(case["num_nodes"])
+    g = torch.Generator().manual_seed(feat_seed)
+    x = torch.randn(n, dims[0], generator=g)
+    y = torch.randint(0, dims[-1], (n,), generator=g)
+    layers = make_layers(dims, "mean", layer_seed)
+    ei = case["edge_index"].astype(np.int64)
+    colptr, row, _ = csc.to_csc(ei, n)
+    node = case["node"].astype(np.int64)
+    rng_seed, counter = int(case["rng_seed"]), int(case["counter"])
+    pos = sampler.random_neighbor(colptr, row, node, rng_seed, counter)
+    neg = sampler.random_nodes(n, len(node), rng_seed, counter)
+    B = len(case["seeds"])
+    e2 = torch.from_numpy(np.stack([case["src"].astype(np.int64), case["dst"].astype(np.int64)]))
+    out = dict(pos=pos.astype(np.int32), neg=neg.astype(np.int32), dims=np.array(dims, dtype=np.int64),
+               lr=np.float32(lr))
+    for tag, with_sup in (("unsup", False), ("both", True)):
+        leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
+        outs = [sage_ref.graphsage_forward(x[torch.from_numpy(ids)], e2, leaf)[:B] for ids in (node, pos, neg)]
+        loss = sage_ref.unsup_loss(*outs)
+        if with_sup:
+            loss = loss + torch.nn.functional.cross_entropy(outs[0], y[torch.from_numpy(node[:B])])
+        loss.backward()
+        out[f"loss_{tag}"] = np.float32(loss.detach())
+        for i, lf in enumerate(leaf):
+            for k in lf:
+                out[f"g_{tag}_{i}_{k}"] = lf[k].grad.numpy()
+    return out
+
+
 def main():
     small = sampler_case(300, 2400, 5, 2, 40, [4, 3], graph_seed=5, rng_seed=21, counter=9, dup=True)
     np.savez_compressed(os.path.join(HERE, "sampler_small.npz"), **small)
@@ -76,6 +109,8 @@ def main():
     for agg in ("mean", "max", "max_pool", "gcn"):
         m = model_case(small, agg, [12, 8, 4], feat_seed=31, layer_seed=32)
         np.savez_compressed(os.path.join(HERE, f"model_small_{agg}.npz"), **m)
+    # same features / labels / weights as model_small_mean.npz (feat_seed 31, layer_seed 32)
+    np.savez_compressed(os.path.join(HERE, "unsup_small.npz"), **unsup_case(small, [12, 8, 4], 31, 32))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

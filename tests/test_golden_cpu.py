@@ -67,3 +67,37 @@ def test_oracle_step_reproduces_golden(path):
     for i, p in enumerate(layers):
         for k, v in p.items():
             np.testing.assert_allclose(v.grad.numpy(), g[f"g{i}_{k}"], rtol=1e-4, atol=1e-7)
+
+
+def test_oracle_unsup_step_reproduces_golden():
+    """unsup_small.npz: positive / negative ids bit-exact, the unsupervised loss (alone and added to
+    the cross entropy) and its gradients, on the batch of sampler_small.npz with the weights of
+    model_small_mean.npz."""
+    u = np.load(os.path.join(GOLD, "unsup_small.npz"))
+    s = np.load(os.path.join(GOLD, "sampler_small.npz"))
+    m = np.load(os.path.join(GOLD, "model_small_mean.npz"))
+    n = int(s["num_nodes"])
+    colptr, row, _ = csc.to_csc(s["edge_index"].astype(np.int64), n)
+    node = s["node"].astype(np.int64)
+    seed, counter = int(s["rng_seed"]), int(s["counter"])
+    pos = sampler.random_neighbor(colptr, row, node, seed, counter)
+    neg = sampler.random_nodes(n, len(node), seed, counter)
+    assert pos.tolist() == u["pos"].tolist() and neg.tolist() == u["neg"].tolist()
+    has = colptr[node + 1] > colptr[node]
+    assert all(p in row[colptr[v]:colptr[v + 1]] for v, p in zip(node[has], pos[has]))   # an in-neighbour
+    assert (pos[~has] == node[~has]).all()                                            # isolated: itself
+    x, y = torch.from_numpy(m["x"]), torch.from_numpy(m["y"])
+    B = len(s["seeds"])
+    ei = torch.from_numpy(np.stack([s["src"].astype(np.int64), s["dst"].astype(np.int64)]))
+    for tag in ("unsup", "both"):
+        layers = [{k[len(f"w{i}_"):]: torch.from_numpy(m[k]).clone().requires_grad_(True)
+                   for k in m.files if k.startswith(f"w{i}_")} for i in range(2)]
+        outs = [sage_ref.graphsage_forward(x[torch.from_numpy(ids)], ei, layers)[:B] for ids in (node, pos, neg)]
+        loss = sage_ref.unsup_loss(*outs)
+        if tag == "both":
+            loss = loss + torch.nn.functional.cross_entropy(outs[0], y[torch.from_numpy(node[:B])])
+        loss.backward()
+        np.testing.assert_allclose(float(loss.detach()), float(u[f"loss_{tag}"]), rtol=1e-6)
+        for i, p in enumerate(layers):
+            for k, v in p.items():
+                np.testing.assert_allclose(v.grad.numpy(), u[f"g_{tag}_{i}_{k}"], rtol=1e-4, atol=1e-7)

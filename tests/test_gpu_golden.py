@@ -130,3 +130,40 @@ def test_engine_step_matches_golden(dev):
         np.testing.assert_allclose(engine.gviews[m.lin_r.weight].cpu().numpy(), g[f"g{i}_lin_r"], rtol=1e-3, atol=1e-6)
         np.testing.assert_allclose(m.lin_l.weight.detach().cpu().numpy(), g[f"a{i}_lin_l"], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(m.lin_r.weight.detach().cpu().numpy(), g[f"a{i}_lin_r"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("unsup,tag", [(True, "both"), ("only", "unsup")])
+def test_engine_unsup_step_matches_golden(dev, unsup, tag):
+    """The trainers' steps on the engine against unsup_small.npz: positive / negative ids
+    bit-exact, loss rtol 1e-5, gradients rtol 1e-3."""
+    from graphsage_amd.data import Data
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    g = np.load(os.path.join(GOLD, "model_small_mean.npz"))
+    s = np.load(os.path.join(GOLD, "sampler_small.npz"))
+    u = np.load(os.path.join(GOLD, "unsup_small.npz"))
+    dims = g["dims"].tolist()
+    data = Data(x=torch.from_numpy(g["x"]), y=torch.from_numpy(g["y"]),
+                edge_index=torch.from_numpy(s["edge_index"].astype(np.int64)))
+    model = GraphSAGE(dims[0], dims[1], "mean", 2, dims[-1]).to(dev)
+    with torch.no_grad():
+        for i, m in enumerate(model.layers):
+            m.lin_l.weight.copy_(torch.from_numpy(g[f"w{i}_lin_l"]))
+            m.lin_r.weight.copy_(torch.from_numpy(g[f"w{i}_lin_r"]))
+    graph = device_graph(data)
+    B = len(s["seeds"])
+    engine = SageTrainEngine(model, NeighborSampler(data, s["fanout"].tolist(), seed=int(s["rng_seed"])),
+                             graph.features(data), graph.labels(data), B, lr=float(u["lr"]), keep_grads=True,
+                             unsup=unsup)
+    loss = engine.step(torch.from_numpy(s["seeds"]).to(dev), counter=int(s["counter"]))
+    nn = int(engine.buf.state[0])
+    assert engine.pos_id[:nn].cpu().numpy().tolist() == u["pos"].tolist()
+    assert engine.neg_id[:nn].cpu().numpy().tolist() == u["neg"].tolist()
+    np.testing.assert_allclose(float(loss), float(u[f"loss_{tag}"]), rtol=1e-5)
+    for i, m in enumerate(model.layers):
+        np.testing.assert_allclose(engine.gviews[m.lin_l.weight].cpu().numpy(), u[f"g_{tag}_{i}_lin_l"],
+                                   rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(engine.gviews[m.lin_r.weight].cpu().numpy(), u[f"g_{tag}_{i}_lin_r"],
+                                   rtol=1e-3, atol=1e-6)
