@@ -70,8 +70,8 @@ class GatherReduceFn(Function):
             return None, None, None, None, None, None
         if mapped:
             raise RuntimeError("gradient w.r.t. a node_map'ed feature table is not supported")
-        dx = torch.zeros(xshape, dtype=torch.float32, device=dout.device)
-        ops.gather_reduce_bwd(dout.contiguous(), seg_ptr, src, num_targets, reduce, dx,
+        dx = ops.empty_rows(xshape[0], xshape[1], dout.device, zero=True)
+        ops.gather_reduce_bwd(ops.aligned_rows(dout), seg_ptr, src, num_targets, reduce, dx,
                               argmax=argmax if has_arg else None)
         return dx, None, None, None, None, None
 
@@ -81,11 +81,14 @@ class LinearConcatFn(Function):
 
     @staticmethod
     def forward(ctx, a1, w1, a2, w2, bias, rows1, rows2, relu, m):
-        a1 = a1 if a1.stride(-1) == 1 else a1.contiguous()
-        if a2 is not None and a2.stride(-1) != 1:
-            a2 = a2.contiguous()
-        w1 = w1.contiguous()
-        w2 = w2.contiguous() if w2 is not None else None
+        # rows that cannot be read 16 bytes at a time (F = 602 with stride 602) cost the GEMM ~1.7x:
+        # re-lay weights and un-mapped operands with padded rows first (a mapped operand is a whole
+        # feature table: the loader already keeps that one padded)
+        a1 = ops.aligned_rows(a1) if rows1 is None else (a1 if a1.stride(-1) == 1 else a1.contiguous())
+        if a2 is not None:
+            a2 = ops.aligned_rows(a2) if rows2 is None else (a2 if a2.stride(-1) == 1 else a2.contiguous())
+        w1 = ops.aligned_rows(w1)
+        w2 = ops.aligned_rows(w2) if w2 is not None else None
         out = ops.linear_concat_fwd(a1, w1, a2, w2, bias=bias, relu=relu, m=m, rows1=rows1, rows2=rows2)
         ctx.save_for_backward(a1, w1, a2 if a2 is not None else a1, w2 if w2 is not None else w1,
                               rows1 if rows1 is not None else w1, rows2 if rows2 is not None else w1,
@@ -98,9 +101,10 @@ class LinearConcatFn(Function):
     def backward(ctx, dout):
         a1, w1, a2, w2, rows1, rows2, out = ctx.saved_tensors
         has2, has_r1, has_r2, relu, has_bias, m = ctx.meta
-        g = dout.contiguous()
+        g = dout
         if relu:
-            g = g * (out > 0).to(g.dtype)
+            g = torch.ops.aten.threshold_backward(dout, out, 0.0)      # dout * [out > 0], one pass
+        g = ops.aligned_rows(g)
         need = ctx.needs_input_grad
         da1 = dw1 = da2 = dw2 = dbias = None
         if has_bias and need[4]:

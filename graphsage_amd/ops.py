@@ -36,6 +36,28 @@ def _p(t, dtype, name, allow_none=False):
     return c_void_p(t.data_ptr())
 
 
+def empty_rows(m, n, device, dtype=torch.float32, zero=False):
+    """[m, n] matrix whose rows start 64-byte aligned: a view of a buffer with the row stride
+    rounded up to 16 elements when n is not a multiple of 4 (e.g. 602 -> 608), so that every
+    kernel takes its 16-byte vector path on it (the 8-byte variants of the GEMM are ~1.7x slower)."""
+    make = torch.zeros if zero else torch.empty
+    if n % 4 == 0 or dtype != torch.float32:
+        return make((m, n), dtype=dtype, device=device)
+    ld = (n + 15) // 16 * 16
+    return make((m, ld), dtype=dtype, device=device)[:, :n]
+
+
+def aligned_rows(t):
+    """t itself if its rows can be read 16 bytes at a time, else a row-padded copy (empty_rows)."""
+    if t.dim() != 2 or t.dtype != torch.float32:
+        return t
+    if t.stride(1) == 1 and t.data_ptr() % 16 == 0 and (t.size(0) <= 1 or t.stride(0) % 4 == 0):
+        return t
+    out = empty_rows(t.size(0), t.size(1), t.device)
+    out.copy_(t)
+    return out
+
+
 def _mat(t, name):
     """2-D fp32 matrix with unit column stride -> (pointer, row stride)."""
     if t.dim() != 2 or (t.size(1) > 1 and t.stride(1) != 1):
@@ -259,7 +281,8 @@ def gather_rows(table, index, num_rows=None, num_rows_dev=None, out=None, checke
     width = t2.size(1) * words
     ld_table = (t2.stride(0) if t2.size(0) > 1 else t2.size(1)) * words
     if out is None:
-        out = torch.empty((n, t2.size(1)), dtype=table.dtype, device=table.device)
+        out = empty_rows(n, t2.size(1), table.device, table.dtype) if table.dim() == 2 else \
+            torch.empty((n, t2.size(1)), dtype=table.dtype, device=table.device)
     o2 = out.unsqueeze(1) if out.dim() == 1 else out
     if o2.size(0) < n or o2.size(1) != t2.size(1) or o2.dtype != table.dtype or \
             (o2.size(1) > 1 and o2.stride(1) != 1):
@@ -288,7 +311,7 @@ def gather_reduce_fwd(x, seg_ptr, src, num_targets, reduce, node_map=None,
     if seg_ptr.numel() < T + 1:
         raise RuntimeError("gather_reduce_fwd: seg_ptr shorter than num_targets+1")
     if out is None:
-        out = torch.empty((T, F), dtype=torch.float32, device=x.device)
+        out = empty_rows(T, F, x.device)
     op, ld_out = _mat(out, "out")
     if out.size(0) < T or out.size(1) != F:
         raise RuntimeError("gather_reduce_fwd: bad output buffer")
@@ -404,7 +427,7 @@ def linear_concat_fwd(a1, w1, a2=None, w2=None, bias=None, relu=False, m=None, m
         if rows2 is None and a2.size(0) < m:
             raise RuntimeError("linear_concat_fwd: a2 has fewer than m rows")
     if out is None:
-        out = torch.empty((m, n), dtype=torch.float32, device=a1.device)
+        out = empty_rows(m, n, a1.device)
     op, ld_out = _mat(out, "out")
     if out.size(0) < m or out.size(1) != n:
         raise RuntimeError("linear_concat_fwd: bad output buffer")
@@ -435,7 +458,7 @@ def linear_dinput(dout, w, m=None, m_dev=None, out=None, accumulate=False):
     if out is None:
         if accumulate:
             raise RuntimeError("linear_dinput: accumulate needs an output buffer")
-        out = torch.empty((m, k), dtype=torch.float32, device=dout.device)
+        out = empty_rows(m, k, dout.device)
     op, ld_da = _mat(out, "da")
     if out.size(0) < m or out.size(1) != k:
         raise RuntimeError("linear_dinput: bad output buffer")
