@@ -42,7 +42,11 @@ gemm_lds_direct(const float* __restrict__ A, const float* __restrict__ B, float*
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int c = wave * 6 + j;
+#ifndef NO_LOADS
       __builtin_amdgcn_global_load_lds((gptr_t)(src[j] + step * BK), (lptr_t)(st + c * 256), 16, 0, 0);
+#else
+      (void)st; (void)c;
+#endif
     }
   };
 
@@ -57,7 +61,11 @@ gemm_lds_direct(const float* __restrict__ A, const float* __restrict__ B, float*
   // that does the same
   auto rd = [](unsigned addr) -> f4v {
     f4v v;
+#ifdef NO_LDS
+    v = f4v{1.f, 2.f, 3.f, (float)addr};      // no LDS read at all: what the MFMA stream alone takes
+#else
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+#endif
     return v;
   };
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
@@ -95,9 +103,13 @@ gemm_lds_direct(const float* __restrict__ A, const float* __restrict__ B, float*
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+#ifndef NO_VMWAIT
     if (t + 2 < nsteps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifndef NO_BARRIER
     __builtin_amdgcn_s_barrier();
+#endif
   }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
