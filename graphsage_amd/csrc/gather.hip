@@ -210,7 +210,23 @@ gather_reduce_fwd_kernel(const float* __restrict__ x, int64_t ld_x,
     }
   }
 
-  const float cnt = len > 0 ? static_cast<float>(len) : 1.f;
+  float cnt = len > 0 ? static_cast<float>(len) : 1.f;
+  if (REDUCE == SAGE_REDUCE_GCN && len > 0) {
+    // one self-loop, appended after the neighbours (reference layers/sage.py:114-117): the
+    // target's own row is added last and counted
+    const int64_t self = node_map != nullptr ? node_map[t] : t;
+    const V* rowp = reinterpret_cast<const V*>(x + self * ld_x + slab0);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      if (live[c]) {
+        float a[VEC];
+        vec_to_arr<VEC>(rowp[c * kWave + lane], a);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[c][j] += a[j];
+      }
+    }
+    cnt += 1.f;
+  }
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
     if (!live[c]) continue;
@@ -218,7 +234,7 @@ gather_reduce_fwd_kernel(const float* __restrict__ x, int64_t ld_x,
     float a[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      a[j] = (REDUCE == SAGE_REDUCE_MEAN) ? acc[c][j] / cnt : acc[c][j];
+      a[j] = (REDUCE == SAGE_REDUCE_MEAN || REDUCE == SAGE_REDUCE_GCN) ? acc[c][j] / cnt : acc[c][j];
     }
     *reinterpret_cast<V*>(out + t * ld_out + f) = arr_to_vec<VEC>(a);
     if (REDUCE == SAGE_REDUCE_MAX && argmax != nullptr) {
@@ -248,13 +264,20 @@ gather_reduce_bwd_kernel(const float* __restrict__ dout, int64_t ld_dout,
   const int64_t s0 = seg_ptr[t];
   const int64_t len = seg_ptr[t + 1] - s0;
   if (len <= 0) return;
-  const float cnt = static_cast<float>(len);
+  // mean: 0 = sum, 1 = mean, 2 = gcn (mean over the neighbours and one self-loop)
+  const float cnt = static_cast<float>(mean == 2 ? len + 1 : len);
   float g[NV];
 #pragma unroll
   for (int c = 0; c < NV; ++c) {
     const int f = slab0 + c * kWave + lane;
     g[c] = f < num_features ? dout[t * ld_dout + f] : 0.f;
     if (mean) g[c] = g[c] / cnt;
+  }
+  if (mean == 2) {   // the self-loop's share goes to the target's own row
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      if (slab0 + c * kWave + lane < num_features) atomicAdd(dx + t * ld_dx + slab0 + c * kWave + lane, g[c]);
+    }
   }
   for (int64_t base = 0; base < len; base += kWave) {
     const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
@@ -405,6 +428,8 @@ int launch_fwd(const float* x, int64_t ld_x, const int64_t* node_map, const int6
     SAGE_LAUNCH_FWD(SAGE_REDUCE_MEAN);
   } else if (reduce == SAGE_REDUCE_SUM) {
     SAGE_LAUNCH_FWD(SAGE_REDUCE_SUM);
+  } else if (reduce == SAGE_REDUCE_GCN) {
+    SAGE_LAUNCH_FWD(SAGE_REDUCE_GCN);
   } else {
     SAGE_LAUNCH_FWD(SAGE_REDUCE_MAX);
   }
@@ -436,7 +461,8 @@ int gather_reduce_fwd_impl(const float* x, sage_i64 ld_x, const sage_i64* node_m
                            float* out, sage_i64 ld_out, sage_i64* argmax, const LaunchEvents& ev,
                            void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX,
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX ||
+                   reduce == SAGE_REDUCE_GCN,
                SAGE_EINVAL, "sage_gather_reduce_fwd: unknown reduce %d", reduce);
   SAGE_REQUIRE(num_features > 0 && ld_x >= num_features && ld_out >= num_features && num_targets >= 0,
                SAGE_EINVAL, "sage_gather_reduce_fwd: bad shape (T=%lld F=%d ld_x=%lld ld_out=%lld)",
@@ -494,7 +520,8 @@ extern "C" int sage_gather_reduce_bwd(const float* dout, sage_i64 ld_dout, const
                                       int num_features, int reduce, float* dx, sage_i64 ld_dx,
                                       void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX,
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX ||
+                   reduce == SAGE_REDUCE_GCN,
                SAGE_EINVAL, "sage_gather_reduce_bwd: unknown reduce %d", reduce);
   SAGE_REQUIRE(num_features > 0 && ld_dout >= num_features && ld_dx >= num_features && num_targets >= 0,
                SAGE_EINVAL, "sage_gather_reduce_bwd: bad shape");
@@ -507,7 +534,7 @@ extern "C" int sage_gather_reduce_bwd(const float* dout, sage_i64 ld_dout, const
     SAGE_CHECK_LAUNCH("gather_max_bwd_kernel");
     return SAGE_OK;
   }
-  const int mean = reduce == SAGE_REDUCE_MEAN;
+  const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : (reduce == SAGE_REDUCE_GCN ? 2 : 0);
   int nv = static_cast<int>(cdiv(num_features, kWave));
   if (nv > 4) nv = 4;
   dim3 grid(static_cast<unsigned>(cdiv(num_targets, kWavesPerBlock)),

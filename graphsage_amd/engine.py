@@ -19,7 +19,7 @@ import torch
 from . import _lib, ops
 from .dist import all_reduce_flat
 
-_REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max'}
+_REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max', 'gcn': 'gcn'}   # gcn: no root weight (lin_r)
 
 
 def flatten_parameters(model, pad_to=16):
@@ -80,6 +80,7 @@ class SageTrainEngine:
             raise NotImplementedError(f"engine supports {sorted(_REDUCE)}, got {model.aggregator}")
         self.model = model
         self.reduce = _REDUCE[model.aggregator]
+        self.root = model.aggregator != 'gcn'      # gcn layers have no lin_r (reference layers/sage.py:62-65)
         self.features, self.labels = features, labels
         self.B = int(batch_size)
         self.L = len(model.layers)
@@ -369,8 +370,9 @@ class SageTrainEngine:
             # the consumer hands it back zeroed (clear_z of the normalise kernel, of the fused
             # loss kernel in the supervised step), so there is no fill kernel.  Only the unsup
             # variants' logit layer has no clearing consumer.
-            lib.linear_concat_fwd(agg, layer.lin_l.weight, x, layer.lin_r.weight, m=t_cap,
-                                  m_dev=t_dev, rows2=node_map, out=a['z'],
+            lib.linear_concat_fwd(agg, layer.lin_l.weight, x if self.root else None,
+                                  layer.lin_r.weight if self.root else None, m=t_cap,
+                                  m_dev=t_dev, rows2=node_map if self.root else None, out=a['z'],
                                   accumulate=(i < L - 1 or not self.unsup))
             if i < L - 1:
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'],
@@ -427,13 +429,19 @@ class SageTrainEngine:
                                     clear_dh=True)   # dh is zero again for the next step's scatter-add
             x_in = self.features if i == 0 else act[i - 1]['h']
             rows = self._node_map(slot, v) if i == 0 else None
-            lib.linear_dweight2(a['dz'], self._agg0(slot, v) if i == 0 else a['agg'],
-                                self.gviews[layer.lin_l.weight], x_in, self.gviews[layer.lin_r.weight],
-                                m=t_cap, m_dev=t_dev, rows2=rows)
+            agg_i = self._agg0(slot, v) if i == 0 else a['agg']
+            if self.root:
+                lib.linear_dweight2(a['dz'], agg_i, self.gviews[layer.lin_l.weight], x_in,
+                                    self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
+            else:
+                lib.linear_dweight(a['dz'], agg_i, m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
             if i > 0:
                 prev = act[i - 1]
-                lib.linear_dinput2(a['dz'], layer.lin_r.weight, prev['dh'], layer.lin_l.weight, a['dagg'],
-                                   m=t_cap, m_dev=t_dev)
+                if self.root:
+                    lib.linear_dinput2(a['dz'], layer.lin_r.weight, prev['dh'], layer.lin_l.weight, a['dagg'],
+                                       m=t_cap, m_dev=t_dev)
+                else:      # the self-loop's share reaches prev['dh'][t] through the gcn scatter below
+                    lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       argmax=a.get('argmax'), num_targets_dev=t_dev)
 

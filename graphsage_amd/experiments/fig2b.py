@@ -50,7 +50,7 @@ class SampleSizeRunner:
             model = GraphSAGE(in_channels=self.dataset.num_features, hidden_channels=self.hidden_channels,
                               out_channels=self.dataset.num_classes, num_layers=NUM_LAYERS,
                               aggregator=self.aggregator).to(device)
-            engine_ok = self.use_engine and self.aggregator in ('mean', 'sum', 'max')
+            engine_ok = self.use_engine and self.aggregator in ('mean', 'sum', 'max', 'gcn')
             best_result, all_results = SupervisedGraphSageTrainerForNodeLevelTask(
                 data, UniformLoader,
                 dataset_name='fig2b',

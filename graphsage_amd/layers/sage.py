@@ -109,15 +109,9 @@ class SAGE(torch.nn.Module):
                 # mean over the neighbours and ONE self-loop for every target that has an in-edge
                 # (reference layers/sage.py:114-117 appends the loops to edge_index and scatters):
                 # (sum_j x_j + x_t) / (deg_t + 1) if deg_t > 0 else 0 — same values, same order of
-                # summation (the loops are appended last), no edge list rewrite, prunable
-                s = SF.gather_reduce(feats, plan.seg_ptr, plan.src, num_targets, 'sum', node_map=fmap)
-                deg = (plan.seg_ptr[1:num_targets + 1] - plan.seg_ptr[:num_targets]).to(s.dtype).unsqueeze(1)
-                if node_map is None:
-                    self_rows = x_src[:num_targets]
-                else:
-                    from .. import ops
-                    self_rows = ops.gather_rows(x_src, node_map[:num_targets], checked=True)  # sampler ids
-                agg = torch.where(deg > 0, (s + self_rows) / (deg + 1.0), torch.zeros_like(s))
+                # summation (the loops are appended last), inside the gather kernel
+                # (SAGE_REDUCE_GCN): no edge list rewrite, prunable
+                agg = SF.gather_reduce(feats, plan.seg_ptr, plan.src, num_targets, 'gcn', node_map=fmap)
             else:
                 agg = SF.gather_reduce(feats, plan.seg_ptr, plan.src, num_targets,
                                        _REDUCE[self.aggregator], node_map=fmap)

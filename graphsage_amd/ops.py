@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2}
+REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2, "gcn": 3}
 EPI_NONE, EPI_BIAS, EPI_RELU, EPI_ACCUM = 0, 1, 2, 4
 
 ST_NODES, ST_EDGES, ST_FRONT_BEGIN, ST_FRONT_END, ST_ERROR = 0, 1, 2, 3, 4
@@ -316,6 +316,8 @@ def gather_reduce_fwd(x, seg_ptr, src, num_targets, reduce, node_map=None,
     if out.size(0) < T or out.size(1) != F:
         raise RuntimeError("gather_reduce_fwd: bad output buffer")
     red = REDUCE[reduce]
+    if red == 3 and (node_map.numel() if node_map is not None else x.size(0)) < T:
+        raise RuntimeError("gather_reduce_fwd: gcn reads the targets' own rows: they must be rows of x (node_map)")
     if want_argmax is None:
         want_argmax = red == 2
     if red == 2 and want_argmax:

@@ -48,6 +48,8 @@ typedef int64_t sage_i64;
 #define SAGE_REDUCE_SUM 0
 #define SAGE_REDUCE_MEAN 1
 #define SAGE_REDUCE_MAX 2
+#define SAGE_REDUCE_GCN 3 /* mean over the neighbours and ONE self-loop, for targets that have an
+                             in-edge (aggregator 'gcn', layers/sage.py:62-65, :114-117) */
 
 /* epilogue flags of sage_linear_concat_fwd */
 #define SAGE_EPI_NONE 0
@@ -182,7 +184,8 @@ int sage_gather_rows(const void* table, sage_i64 ld_table, const sage_i64* index
  *     out[t, :] = reduce_{e in [seg_ptr[t], seg_ptr[t+1])} X[row_of(src[e]), :]
  * row_of(s) = node_map ? node_map[s] : s   (node_map = the batch's `node` vector, so the
  * gather reads the global feature table directly instead of a materialised batch.x).
- * Empty segments give 0 for all three reduces; mean divides by max(count,1).
+ * Empty segments give 0 for every reduce; mean divides by max(count,1).  SAGE_REDUCE_GCN adds the
+ * target's own row X[row_of(t), :] after its neighbours and divides by count + 1 (count > 0).
  * max also writes argmax[t, f] = the edge index e that supplied the maximum (first such
  * edge in segment order on ties), or -1 for an empty segment; argmax may be NULL.
  * ---------------------------------------------------------------------------------- */
@@ -207,6 +210,7 @@ int sage_gather_reduce_fwd_timed(const float* x, sage_i64 ld_x, const sage_i64* 
 /* Backward of the above w.r.t. x (autograd of scatter + index_select):
  *   sum : dx[src[e], :] += dout[t, :]            mean: += dout[t, :] / max(count_t, 1)
  *   max : dx[src[argmax[t,f]], f] += dout[t, f]  (argmax >= 0)
+ *   gcn : += dout[t, :] / (count_t + 1) to every dx[src[e], :] AND to dx[t, :]  (count_t > 0)
  * dx must be pre-initialised (zero, or a gradient to accumulate into); adds are fp32
  * atomics, so the summation order — not the set of addends — may vary between runs. */
 int sage_gather_reduce_bwd(const float* dout, sage_i64 ld_dout, const sage_i64* seg_ptr,

@@ -142,6 +142,36 @@ def test_gather_reduce_timed_launch(dev):
         ops.gather_reduce_fwd(table, seg_ptr, src, T, "mean", node_map=node, events=(0, 0))
 
 
+@pytest.mark.parametrize("F,mapped", [(602, True), (256, False), (50, False)])
+def test_gather_reduce_gcn(dev, F, mapped):
+    """SAGE_REDUCE_GCN: mean over the neighbours and one self-loop for targets with an in-edge
+    (reference layers/sage.py:114-117: loops appended to edge_index, then scatter-mean), forward
+    against the oracle's scatter over the extended edge list, backward against autograd."""
+    from graphsage_amd import ops
+    T, S, N = 300, 400, 1500
+    src, dst = _segments(T, 30, S, seed=F)
+    g = torch.Generator().manual_seed(7)
+    table = torch.randn(N if mapped else S, F, generator=g)
+    node = torch.randperm(N, generator=g)[:S] if mapped else None
+    x = table[node] if mapped else table
+    seg_ptr = torch.zeros(T + 1, dtype=torch.int64)
+    seg_ptr[1:] = torch.bincount(dst, minlength=T).cumsum(0)
+    loops = torch.unique(dst)
+    src2, dst2 = torch.cat([src, loops]), torch.cat([dst, loops])
+    xg = x.clone().requires_grad_(True)
+    want = sage_ref.scatter_ref(xg[src2], dst2, T, "mean")
+    out, _ = ops.gather_reduce_fwd(_padded(table, dev, True), seg_ptr.to(dev), src.to(dev), T, "gcn",
+                                   node_map=node.to(dev) if mapped else None)
+    torch.testing.assert_close(out.cpu(), want.detach(), rtol=RTOL, atol=ATOL)
+    assert bool((out.cpu()[seg_ptr[1:] == seg_ptr[:-1]] == 0).all())          # no in-edge: no self-loop either
+    if not mapped:
+        dout = torch.randn(T, F, generator=g)
+        want.backward(dout)
+        dx = torch.zeros(S, F, device=dev)
+        ops.gather_reduce_bwd(dout.to(dev), seg_ptr.to(dev), src.to(dev), T, "gcn", dx)
+        torch.testing.assert_close(dx.cpu(), xg.grad, rtol=1e-4, atol=1e-5)
+
+
 def test_gather_reduce_long_segments_and_kats(dev):
     from graphsage_amd import ops
     # one target with 1000 edges (several 64-edge chunks), duplicates counted twice, negatives

@@ -99,23 +99,25 @@ def test_step_matches_golden(dev, path):
                 np.testing.assert_allclose(get(m).detach().cpu().numpy(), g[f"a{i}_{k}"], rtol=1e-4, atol=1e-6)
 
 
-def test_engine_step_matches_golden(dev):
+@pytest.mark.parametrize("agg", ["mean", "max", "gcn"])
+def test_engine_step_matches_golden(dev, agg):
     """The static-shape engine (sampler + fused forward/backward + device Adam) on the golden batch."""
     from graphsage_amd.data import Data
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import NeighborSampler
     from graphsage_amd.samplers.uniform_loader import device_graph
-    g = np.load(os.path.join(GOLD, "model_small_mean.npz"))
+    g = np.load(os.path.join(GOLD, f"model_small_{agg}.npz"))
     s = np.load(os.path.join(GOLD, "sampler_small.npz"))
     dims = g["dims"].tolist()
     data = Data(x=torch.from_numpy(g["x"]), y=torch.from_numpy(g["y"]),
                 edge_index=torch.from_numpy(s["edge_index"].astype(np.int64)))
-    model = GraphSAGE(dims[0], dims[1], "mean", 2, dims[-1]).to(dev)
+    model = GraphSAGE(dims[0], dims[1], agg, 2, dims[-1]).to(dev)
     with torch.no_grad():
         for i, m in enumerate(model.layers):
             m.lin_l.weight.copy_(torch.from_numpy(g[f"w{i}_lin_l"]))
-            m.lin_r.weight.copy_(torch.from_numpy(g[f"w{i}_lin_r"]))
+            if agg != "gcn":
+                m.lin_r.weight.copy_(torch.from_numpy(g[f"w{i}_lin_r"]))
     graph = device_graph(data)
     B = len(s["seeds"])
     engine = SageTrainEngine(model, NeighborSampler(data, s["fanout"].tolist(), seed=int(s["rng_seed"])),
@@ -127,8 +129,11 @@ def test_engine_step_matches_golden(dev):
     np.testing.assert_allclose(engine.act[-1]["y"][:B].cpu().numpy(), g["y_hat"], rtol=1e-4, atol=2e-5)
     for i, m in enumerate(model.layers):
         np.testing.assert_allclose(engine.gviews[m.lin_l.weight].cpu().numpy(), g[f"g{i}_lin_l"], rtol=1e-3, atol=1e-6)
-        np.testing.assert_allclose(engine.gviews[m.lin_r.weight].cpu().numpy(), g[f"g{i}_lin_r"], rtol=1e-3, atol=1e-6)
         np.testing.assert_allclose(m.lin_l.weight.detach().cpu().numpy(), g[f"a{i}_lin_l"], rtol=1e-4, atol=1e-6)
+        if agg == "gcn":
+            assert not hasattr(m, "lin_r")
+            continue
+        np.testing.assert_allclose(engine.gviews[m.lin_r.weight].cpu().numpy(), g[f"g{i}_lin_r"], rtol=1e-3, atol=1e-6)
         np.testing.assert_allclose(m.lin_r.weight.detach().cpu().numpy(), g[f"a{i}_lin_r"], rtol=1e-4, atol=1e-6)
 
 
