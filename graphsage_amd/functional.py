@@ -31,6 +31,16 @@ class EdgePlan:
 def plan_for(edge_index, num_src, num_dst):
     """Plan attached by the loader, or built (and cached on the tensor) for any edge_index."""
     plan = getattr(edge_index, "_sage_plan", None)
+    if not isinstance(edge_index, torch.Tensor) or edge_index.layout != torch.strided:
+        if plan is None:
+            plan = _plan_from_adj_t(edge_index, num_src, num_dst)
+            try:
+                edge_index._sage_plan = plan
+            except Exception:
+                pass
+        if plan.num_dst < num_dst:
+            raise RuntimeError(f"adj_t has {plan.num_dst} rows, the layer needs {num_dst} targets")
+        return plan
     key = (edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
     if plan is not None and (plan.key is None or plan.key == key) and plan.num_dst >= num_dst:
         return plan
@@ -51,6 +61,36 @@ def plan_for(edge_index, num_src, num_dst):
     except Exception:  # tensors that refuse attributes: just do not cache
         pass
     return plan
+
+
+def _plan_from_adj_t(adj_t, num_src, num_dst):
+    """The SparseTensor form of the layer's input (reference layers/sage.py:107-109, :213-232:
+    `matmul(adj_t, x, reduce)` with adj_t = transposed adjacency, row = target, col = source).
+    Its CSR arrays ARE the target-grouped plan, so nothing is sorted.  Accepts a
+    torch.sparse_csr tensor or any object with torch_sparse's `.csr()` -> (rowptr, col, value);
+    values are ignored as the reference drops them (:218)."""
+    if isinstance(adj_t, torch.Tensor):
+        if adj_t.layout != torch.sparse_csr:
+            raise RuntimeError("sparse edge_index must be a torch.sparse_csr tensor (adj_t: row = target)")
+        rowptr, col = adj_t.crow_indices(), adj_t.col_indices()
+        rows, cols = adj_t.shape[-2], adj_t.shape[-1]
+    elif hasattr(adj_t, "csr"):
+        rowptr, col = adj_t.csr()[:2]
+        rows, cols = rowptr.numel() - 1, num_src
+        if hasattr(adj_t, "sparse_sizes"):
+            rows, cols = adj_t.sparse_sizes()
+    else:
+        raise RuntimeError("edge_index must be an int64 tensor of shape [2, E] or a CSR adjacency (adj_t)")
+    if not rowptr.is_cuda:
+        raise RuntimeError("graphsage_amd runs on the GPU only: move adj_t to the device")
+    rowptr, col = rowptr.to(torch.int64).contiguous(), col.to(torch.int64).contiguous()
+    if rowptr.dim() != 1 or rowptr.numel() != rows + 1 or cols > num_src:
+        raise RuntimeError(f"adj_t of shape [{rows}, {cols}] does not fit {num_src} source rows")
+    if col.numel() > 0:
+        lo, hi, first, last = int(col.min()), int(col.max()), int(rowptr[0]), int(rowptr[-1])
+        if lo < 0 or hi >= num_src or first != 0 or last != col.numel() or bool((rowptr[1:] < rowptr[:-1]).any()):
+            raise RuntimeError("adj_t: column ids out of range or rowptr not a scan of the row lengths")
+    return EdgePlan(rowptr, col, rows, num_src)
 
 
 class GatherReduceFn(Function):

@@ -1,7 +1,7 @@
 """SAGE layer with the reference's module API (reference graphsage/layers/sage.py:17-134):
 
     SAGE(in_channels, out_channels, aggregator='mean', normalize=True, root_weight=True)
-    forward(x | (x_src, x_dst), edge_index[2,E], size=None) -> [N, out_channels]
+    forward(x | (x_src, x_dst), edge_index[2,E] | adj_t (CSR), size=None) -> [N, out_channels]
 
 Parameter names/shapes match (`lin_l.weight`, `lin_r.weight` bias-free [out,in];
 `pool.weight/bias` [in,in]; `lstm.*` — :67-81) so state_dicts interchange.  The arithmetic
@@ -70,10 +70,14 @@ class SAGE(torch.nn.Module):
         if isinstance(x, Tensor):
             x = (x, x)
         x_src, x_dst = x
+        dense = isinstance(edge_index, Tensor) and edge_index.layout == torch.strided
         if x_dst is not None:
             num_dst = x_dst.size(0)
         elif isinstance(size, (tuple, list)) and size[1] is not None:
             num_dst = int(size[1])
+        elif not dense:
+            # adj_t (CSR, row = target): the message_and_aggregate form, reference :213-232
+            num_dst = SF.plan_for(edge_index, x_src.size(0), 0).num_dst
         else:
             num_dst = int(edge_index[1].max()) + 1 if edge_index.numel() else 0
         # (gcn's self-loops, reference layers/sage.py:114-117, are applied arithmetically in

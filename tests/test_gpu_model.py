@@ -43,6 +43,41 @@ def test_sage_layer_forward_backward(dev, aggregator):
         torch.testing.assert_close(layer.pool.bias.grad.cpu(), pr["pool_b"].grad, rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("aggregator", ["mean", "max", "max_pool"])
+def test_sage_layer_adj_t_input(dev, aggregator):
+    """The SparseTensor form (reference layers/sage.py:107-109, :213-232: matmul(adj_t, x, reduce)):
+    a CSR adjacency with row = target gives the same output as the edge list it was built from —
+    as a torch.sparse_csr tensor and as an object with torch_sparse's .csr()."""
+    from graphsage_amd.layers import SAGE
+    n, e, fin, fout = 300, 4000, 50, 16
+    ei = torch.from_numpy(random_graph(n, e, seed=5, isolated=4)).to(dev)
+    x = torch.randn(n, fin, generator=torch.Generator().manual_seed(1)).to(dev)
+    layer = SAGE(fin, fout, aggregator).to(dev)
+    want = layer(x, ei)
+    order = torch.argsort(ei[1], stable=True)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.bincount(ei[1], minlength=n).cumsum(0)
+    col = ei[0][order]
+    adj_t = torch.sparse_csr_tensor(rowptr, col, torch.ones(e, device=dev), size=(n, n))
+    assert torch.equal(layer(x, adj_t), want)
+
+    class Adj:                                   # torch_sparse.SparseTensor's accessors
+        def csr(self):
+            return rowptr, col, None
+
+        def sparse_sizes(self):
+            return n, n
+    xg = x.clone().requires_grad_(True)
+    out = layer(xg, Adj())
+    assert torch.equal(out, want)
+    out.sum().backward()
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad).all())
+    with pytest.raises(RuntimeError):
+        layer(x, torch.sparse_csr_tensor(rowptr, col + n, torch.ones(e, device=dev), size=(n, 2 * n)))
+    with pytest.raises(RuntimeError):
+        layer(x, adj_t.cpu())
+
+
 def test_sage_layer_api_details(dev):
     from graphsage_amd.layers import SAGE
     layer = SAGE(8, 4, 'mean').to(dev)
