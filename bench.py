@@ -203,7 +203,7 @@ def main():
     if args.variant == "unsup":
         C = args.hidden              # the unsupervised runners emit embeddings, not class logits
     model = GraphSAGE(Fdim, args.hidden, args.aggregator, len(K), C).to(dev)
-    init_layers = [{"lin_l": m.lin_l.weight.detach().cpu().clone(), "lin_r": m.lin_r.weight.detach().cpu().clone()}
+    init_layers = [{k: getattr(m, k).weight.detach().cpu().clone() for k in ("lin_l", "lin_r") if hasattr(m, k)}
                    for m in model.layers]
     sampler = NeighborSampler.from_graph(graph, K, seed=0)   # the CSC is already resident
     pg = torch.distributed.group.WORLD if world > 1 else None
