@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -19,10 +20,28 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int BM = 64, BN = 128, BK = 16, NT = 256;
-constexpr int ROWB = 48;                         // bytes per LDS row: 16 bf16 + 16 bytes of padding
+#ifndef BKV
+#define BKV 16
+#endif
+#ifndef NSTAGE
+#define NSTAGE 2
+#endif
+#ifndef WGS
+#define WGS 2
+#endif
+#ifndef BMV
+#define BMV 64
+#endif
+constexpr int BM = BMV, BN = 128, BK = BKV, NT = 256;
+constexpr int TM = BM / 64;
+#ifndef NPROD
+#define NPROD 6      // knock-out: fewer of the six products (wrong numbers, timing only)
+#endif
+constexpr int ROWB = BK * 2 + 16;                // bytes per LDS row: BK bf16 + 16 bytes of padding
 constexpr int PLANE = (BM + BN) * ROWB;          // one plane (hi / mid / lo) of A and B rows
-constexpr int STAGE = 3 * PLANE;                 // 27,648 bytes
+constexpr int STAGE = 3 * PLANE;
+constexpr int UPR = BK / 4;                      // float4 units per row
+constexpr int PASSES = (BM + BN) * UPR / NT;
 
 __device__ inline unsigned cvt_pk(float a, float b) {
   unsigned r;
@@ -32,6 +51,12 @@ __device__ inline unsigned cvt_pk(float a, float b) {
 
 // two floats -> packed bf16 pairs of their hi / mid / lo terms
 __device__ inline void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+#ifdef KO_SPLIT   // knock-out: truncated hi only, no residuals (wrong numbers, timing only)
+  hi = (__float_as_uint(x0) >> 16) | (__float_as_uint(x1) & 0xffff0000u);
+  mid = hi;
+  lo = hi;
+  return;
+#endif
   hi = cvt_pk(x0, x1);
   const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
   mid = cvt_pk(r0, r1);
@@ -39,48 +64,21 @@ __device__ inline void split2(float x0, float x1, unsigned& hi, unsigned& mid, u
   lo = cvt_pk(q0, q1);
 }
 
-__global__ void __launch_bounds__(NT, 2)
+// stream-K: the grid is the number of resident workgroups; each takes an equal range of
+// (tile, K-step) pairs and adds its partial tiles into the zeroed C
+__global__ void __launch_bounds__(NT, WGS)
 gemm_bf16x3(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
             int K) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l31 = lane & 31, half = lane >> 5;
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
-  const long m0 = (long)blockIdx.x * BM, n0 = (long)blockIdx.y * BN;
-
-  // loader: unit u = 4 consecutive k of one row; rows 0..63 = A, 64..191 = B; 4 units per row
-  const float* src[3];
-  int dsto[3];
-#pragma unroll
-  for (int p = 0; p < 3; ++p) {
-    const int u = threadIdx.x + p * NT;          // 0 .. 767
-    const int r = u >> 2, c = (u & 3) * 4;
-    src[p] = (r < BM ? A + (m0 + r) * (long)K : B + (n0 + r - BM) * (long)K) + c;
-    dsto[p] = r * ROWB + c * 2;
-  }
-  float4 v[3];
-  auto issue = [&](int step) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) v[p] = *reinterpret_cast<const float4*>(src[p] + step * BK);
-  };
-  auto store = [&](int stage) {
-    unsigned char* st = lds + stage * STAGE;
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      unsigned h0, m0_, l0, h1, m1, l1;
-      split2(v[p].x, v[p].y, h0, m0_, l0);
-      split2(v[p].z, v[p].w, h1, m1, l1);
-      *reinterpret_cast<u32x2*>(st + dsto[p]) = u32x2{h0, h1};
-      *reinterpret_cast<u32x2*>(st + PLANE + dsto[p]) = u32x2{m0_, m1};
-      *reinterpret_cast<u32x2*>(st + 2 * PLANE + dsto[p]) = u32x2{l0, l1};
-    }
-  };
-
-  floatx16 acc[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * 64;
+  const int S = K / BK, tiles_n = N / BN;
+  const long total = (long)(M / BM) * tiles_n * S;
+  unsigned lb = blockIdx.x;
+  if (gridDim.x % 8 == 0) lb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  long it = total * lb / gridDim.x;
+  const long end = total * (lb + 1) / gridDim.x;
 
   const int offa = (wm0 + l31) * ROWB + half * 16;
   const int offb0 = (BM + wn0 + l31) * ROWB + half * 16, offb1 = offb0 + 32 * ROWB;
@@ -89,37 +87,112 @@ gemm_bf16x3(const float* __restrict__ A, const float* __restrict__ B, float* __r
     return __builtin_bit_cast(bf16x8, w);
   };
 
-  const int nsteps = K / BK;
-  issue(0);
-  store(0);
-  __syncthreads();
-  for (int t = 0; t < nsteps; ++t) {
-    if (t + 1 < nsteps) issue(t + 1);
-    const unsigned char* st = lds + (t & 1) * STAGE;
-    bf16x8 a[3], b0[3], b1[3];
+  while (it < end) {
+    const long tile = it / S;
+    const int u0 = (int)(it - tile * S);
+    const int u1 = end - it < S - u0 ? u0 + (int)(end - it) : S;
+    const long m0 = tile / tiles_n * BM, n0 = tile % tiles_n * BN;
+    it += u1 - u0;
+
+    const float* src[PASSES];
+    int dsto[PASSES];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      a[p] = frag(st + p * PLANE + offa);
-      b0[p] = frag(st + p * PLANE + offb0);
-      b1[p] = frag(st + p * PLANE + offb1);
+    for (int p = 0; p < PASSES; ++p) {
+      const int u = threadIdx.x + p * NT;
+      const int r = u / UPR, c = (u % UPR) * 4;
+      src[p] = (r < BM ? A + (m0 + r) * (long)K : B + (n0 + r - BM) * (long)K) + c;
+      dsto[p] = r * ROWB + c * 2;
     }
-    // smallest terms first
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    // loads run TWO steps ahead in two register sets (set = parity of the step they hold);
+    // requests past the last step are clamped to it and their LDS image is never read
+    float4 v[2][PASSES];
+    auto issue = [&](auto set, int step) {
+      const int sc = step < u1 ? step : u1 - 1;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b0[PB[q]], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b1[PB[q]], acc[1], 0, 0, 0);
-    }
-    if (t + 1 < nsteps) store((t + 1) & 1);
+      for (int p = 0; p < PASSES; ++p) v[decltype(set)::value][p] = *reinterpret_cast<const float4*>(src[p] + sc * BK);
+    };
+    auto store = [&](auto set, int stage) {
+      unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const float4 x = v[decltype(set)::value][p];
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split2(x.x, x.y, h0, m0_, l0);
+        split2(x.z, x.w, h1, m1, l1);
+        *reinterpret_cast<u32x2*>(st + dsto[p]) = u32x2{h0, h1};
+#ifndef KO_LDSW   // knock-out: one plane written instead of three
+        *reinterpret_cast<u32x2*>(st + PLANE + dsto[p]) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(st + 2 * PLANE + dsto[p]) = u32x2{l0, l1};
+#endif
+      }
+    };
+
+    floatx16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto mfmas = [&](const unsigned char* st) {
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 a[TM][3], b0[3], b1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[i][p] = frag(st + p * PLANE + offa + i * 32 * ROWB + 32 * s);
+          b0[p] = frag(st + p * PLANE + offb0 + 32 * s);
+          b1[p] = frag(st + p * PLANE + offb1 + 32 * s);
+        }
+        // smallest terms first
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < NPROD; ++q) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b0[PB[q]], acc[i][0], 0, 0, 0);
+            acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[q]], b1[PB[q]], acc[i][1], 0, 0, 0);
+          }
+        }
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // one step: LDS stage `cur` holds step t, set HOLD holds step t+1, set FREE takes step t+2
+    auto step = [&](auto hold, auto free_, int t, int cur) {
+      issue(free_, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas(lds + (NSTAGE == 2 ? cur : 0) * STAGE);
+      __builtin_amdgcn_sched_barrier(0);
+      if (NSTAGE == 1) __syncthreads();
+      store(hold, NSTAGE == 2 ? cur ^ 1 : 0);
+      __syncthreads();
+    };
+    issue(S0{}, u0);
+    issue(S1{}, u0 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store(S0{}, 0);
     __syncthreads();
-  }
+    int t = u0;
+    for (; t + 1 < u1; t += 2) {
+      step(S1{}, S0{}, t, 0);
+      step(S0{}, S1{}, t + 1, 1);
+    }
+    if (t < u1) step(S1{}, S0{}, t, 0);
+    const bool partial = !(u0 == 0 && u1 == S);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long col = n0 + wn0 + j * 32 + l31;
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const long row = m0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * half;
-      if (row < M && col < N) C[row * N + col] = acc[j][e];
+    for (int j = 0; j < 2; ++j) {
+      const long col = n0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        if (partial) atomicAdd(C + row * N + col, acc[i][j][e]);
+        else C[row * N + col] = C[row * N + col] + acc[i][j][e];
+      }
     }
   }
 }
@@ -145,7 +218,8 @@ int main() {
   CK(hipMalloc(&dc, (size_t)M * N * 4));
   CK(hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
-  dim3 grid(M / BM, N / BN);
+  dim3 grid(256 * WGS);
+  CK(hipMemset(dc, 0, (size_t)M * N * 4));
   gemm_bf16x3<<<grid, NT>>>(da, db, dc, M, N, K);
   CK(hipDeviceSynchronize());
   std::vector<float> c((size_t)M * N);
@@ -178,6 +252,7 @@ int main() {
   const double us = ms * 1e3 / reps;
   printf("max err / sum|a*b|: bf16x3 kernel %.3g, sequential fp32 fma %.3g (2^-24 = %.3g)\n", err_k, err_f,
          ldexp(1.0, -24));
-  printf("%.1f us   %.1f fp32-equivalent TF/s   (%d tiles)\n", us, 2.0 * M * N * K / us * 1e-6, grid.x * grid.y);
-  return err_k < 1e-6 ? 0 : 2;
+  printf("BM %d BK %d stages %d wgs/cu %d: %.1f us   %.1f fp32-equivalent TF/s\n", BM, BK, NSTAGE, WGS, us,
+         2.0 * M * N * K / us * 1e-6);
+  return 0;
 }
