@@ -1,0 +1,229 @@
+// Experiment: the weight-gradient contraction C[M][N] = sum_k A[k][m] * B[k][n] (both operands
+// with the CONTRACTION index as their row index: dz^T . [agg | x]) on the bf16 MFMA with the 3-way
+// operand split of scratch/bf16x3_gemm.hip.  The tiles are staged as they lie in memory, [k][m|n]
+// bf16 planes, and the MFMA fragments (8 consecutive k per lane) come out of LDS through the
+// transposing read ds_read_b64_tr_b16: no register or LDS-write transpose.
+// Build: hipcc -O3 --offload-arch=gfx950 scratch/bf16x3_dweight.hip -o scratch/bf16x3_dweight
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#ifndef WGS
+#define WGS 3
+#endif
+#ifndef NPROD
+#define NPROD 6
+#endif
+constexpr int BM = 64, BN = 128, BK = 32, NT = 256;
+constexpr int ROWB = 448;                        // bytes per LDS row (one k): 192 bf16 + 64 B pad; 112 dwords = 48 mod 64
+constexpr int PLANE = BK * ROWB;                 // 14,336 B
+constexpr int STAGE = 3 * PLANE;                 // 43,008 B
+constexpr int UPR = (BM + BN) / 4;               // 48 float4 units per k row
+constexpr int PASSES = BK * UPR / NT;            // 6
+
+__device__ inline unsigned cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk(r0, r1);
+  const float q0 = r0 - __uint_as_float(mid << 16), q1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk(q0, q1);
+}
+
+__global__ void __launch_bounds__(NT, WGS)
+dweight_bf16x3(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N,
+               int K) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[STAGE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+  const int S = K / BK, tiles_n = N / BN;
+  const long total = (long)(M / BM) * tiles_n * S;
+  unsigned lb = blockIdx.x;
+  if (gridDim.x % 8 == 0) lb = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  long it = total * lb / gridDim.x;
+  const long end = total * (lb + 1) / gridDim.x;
+
+  // transposing reads: lane 4q+p of a 16-lane group addresses row (k) q, columns 4p..4p+3 of a
+  // 4 x 16 block and receives column (l & 15) of it, row q in element q
+  const int grp = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+  const int tr_row = 8 * half + q;                                   // + 16 s + 4 j
+  const int tra = tr_row * ROWB + (wm0 + 16 * grp + p4) * 2;
+  const int trb0 = tr_row * ROWB + (BM + wn0 + 16 * grp + p4) * 2, trb1 = trb0 + 64;
+  typedef __attribute__((address_space(3))) s16x4* lp;
+  auto frag = [&](const unsigned char* base) -> bf16x8 {             // k = 8 half + 0..7 of one k16 block
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(base + 4 * ROWB));
+    const s16x8 w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, w);
+  };
+
+  while (it < end) {
+    const long tile = it / S;
+    const int u0 = (int)(it - tile * S);
+    const int u1 = end - it < S - u0 ? u0 + (int)(end - it) : S;
+    const long m0 = tile / tiles_n * BM, n0 = tile % tiles_n * BN;
+    it += u1 - u0;
+
+    const float* src[PASSES];
+    long kstride[PASSES];
+    int dsto[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const int u = threadIdx.x + p * NT;
+      const int kr = u / UPR, cg = u % UPR;
+      const bool isa = cg < BM / 4;
+      src[p] = isa ? A + (long)kr * M + m0 + 4 * cg : B + (long)kr * N + n0 + 4 * (cg - BM / 4);
+      kstride[p] = (long)BK * (isa ? M : N);
+      dsto[p] = kr * ROWB + cg * 8;
+    }
+    float4 v[2][PASSES];
+    auto issue = [&](auto set, int step) {
+      const int sc = step < u1 ? step : u1 - 1;
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p)
+        v[decltype(set)::value][p] = *reinterpret_cast<const float4*>(src[p] + sc * kstride[p]);
+    };
+    auto store = [&](auto set) {
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) {
+        const float4 x = v[decltype(set)::value][p];
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split2(x.x, x.y, h0, m0_, l0);
+        split2(x.z, x.w, h1, m1, l1);
+        *reinterpret_cast<u32x2*>(lds + dsto[p]) = u32x2{h0, h1};
+        *reinterpret_cast<u32x2*>(lds + PLANE + dsto[p]) = u32x2{m0_, m1};
+        *reinterpret_cast<u32x2*>(lds + 2 * PLANE + dsto[p]) = u32x2{l0, l1};
+      }
+    };
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    auto mfmas = [&]() {
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 a[3], b0[3], b1[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const unsigned char* pl = lds + p * PLANE + 16 * s * ROWB;
+          a[p] = frag(pl + tra);
+          b0[p] = frag(pl + trb0);
+          b1[p] = frag(pl + trb1);
+        }
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+        for (int qq = 0; qq < NPROD; ++qq) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[qq]], b0[PB[qq]], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[qq]], b1[PB[qq]], acc[1], 0, 0, 0);
+        }
+      }
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    // one step: LDS holds step t, set HOLD holds step t+1, set FREE takes step t+2
+    auto step = [&](auto hold, auto free_, int t) {
+      issue(free_, t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      store(hold);
+      __syncthreads();
+    };
+    issue(S0{}, u0);
+    issue(S1{}, u0 + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    store(S0{});
+    __syncthreads();
+    int t = u0;
+    for (; t + 1 < u1; t += 2) {
+      step(S1{}, S0{}, t);
+      step(S0{}, S1{}, t + 1);
+    }
+    if (t < u1) step(S1{}, S0{}, t);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long col = n0 + wn0 + j * 32 + l31;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const long row = m0 + wm0 + (e & 3) + 8 * (e >> 2) + 4 * half;
+        atomicAdd(C + row * N + col, acc[j][e]);
+      }
+    }
+  }
+}
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+int main() {
+  const int M = 256, N = 1280, K = 13312;      // multiples of the tile: no bounds handling in the loader
+  std::vector<float> a((size_t)K * M), b((size_t)K * N);
+  srand(1);
+  for (auto& v : a) v = (rand() % 200001 - 100000) / 1000000.f;
+  for (auto& v : b) v = (rand() % 200001 - 100000) / 100000.f * ((rand() & 7) == 0 ? 37.f : 1.f);
+  float *da, *db, *dc;
+  CK(hipMalloc(&da, a.size() * 4));
+  CK(hipMalloc(&db, b.size() * 4));
+  CK(hipMalloc(&dc, (size_t)M * N * 4));
+  CK(hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+  dim3 grid(256 * WGS);
+  CK(hipMemset(dc, 0, (size_t)M * N * 4));
+  dweight_bf16x3<<<grid, NT>>>(da, db, dc, M, N, K);
+  CK(hipDeviceSynchronize());
+  std::vector<float> c((size_t)M * N);
+  CK(hipMemcpy(c.data(), dc, c.size() * 4, hipMemcpyDeviceToHost));
+  double err_k = 0, err_f = 0;
+  for (int s = 0; s < 600; ++s) {
+    const int r = rand() % M, col = rand() % N;
+    double ref = 0, mag = 0;
+    float f32 = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const double p = (double)a[(size_t)k * M + r] * b[(size_t)k * N + col];
+      ref += p;
+      mag += fabs(p);
+      f32 = fmaf(a[(size_t)k * M + r], b[(size_t)k * N + col], f32);
+    }
+    err_k = fmax(err_k, fabs(ref - c[(size_t)r * N + col]) / mag);
+    err_f = fmax(err_f, fabs(ref - f32) / mag);
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = 20;
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) dweight_bf16x3<<<grid, NT>>>(da, db, dc, M, N, K);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps;
+  printf("max err / sum|a*b|: bf16x3 kernel %.3g, sequential fp32 fma %.3g\n", err_k, err_f);
+  printf("wgs/cu %d products %d: %.1f us   %.1f fp32-equivalent TF/s\n", WGS, NPROD, us, 2.0 * M * N * K / us * 1e-6);
+  return 0;
+}
