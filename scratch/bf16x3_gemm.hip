@@ -108,6 +108,11 @@ gemm_bf16x3(const float* __restrict__ A, const float* __restrict__ B, float* __r
     float4 v[2][PASSES];
     auto issue = [&](auto set, int step) {
       const int sc = step < u1 ? step : u1 - 1;
+#ifdef KO_LOADS   // knock-out: no global loads in the loop (wrong numbers, timing only)
+#pragma unroll
+      for (int p = 0; p < PASSES; ++p) v[decltype(set)::value][p] = make_float4(1.f + sc, 2.f, 3.f, (float)threadIdx.x);
+      return;
+#endif
 #pragma unroll
       for (int p = 0; p < PASSES; ++p) v[decltype(set)::value][p] = *reinterpret_cast<const float4*>(src[p] + sc * BK);
     };
@@ -166,9 +171,13 @@ gemm_bf16x3(const float* __restrict__ A, const float* __restrict__ B, float* __r
       __builtin_amdgcn_sched_barrier(0);
       mfmas(lds + (NSTAGE == 2 ? cur : 0) * STAGE);
       __builtin_amdgcn_sched_barrier(0);
+#ifndef KO_BARRIER   // knock-out: no barriers in the loop (races; timing only)
       if (NSTAGE == 1) __syncthreads();
+#endif
       store(hold, NSTAGE == 2 ? cur ^ 1 : 0);
+#ifndef KO_BARRIER
       __syncthreads();
+#endif
     };
     issue(S0{}, u0);
     issue(S1{}, u0 + 1);
@@ -190,8 +199,14 @@ gemm_bf16x3(const float* __restrict__ A, const float* __restrict__ B, float* __r
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const long row = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+#ifdef KO_EPI      // knock-out: one store per accumulator register set instead of the tile's adds
+        if (e == 0 && acc[i][j][e] == 12345.f) C[row * N + col] = acc[i][j][1];
+#elif defined(EPI_STORE)   // plain stores instead of atomics (wrong sums for split tiles; timing only)
+        C[row * N + col] = acc[i][j][e];
+#else
         if (partial) atomicAdd(C + row * N + col, acc[i][j][e]);
         else C[row * N + col] = C[row * N + col] + acc[i][j][e];
+#endif
       }
     }
   }
