@@ -257,7 +257,7 @@ int main() {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  const int reps = 20;
+  const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 20;   // REPS=30000: seconds of load, to watch clocks / power beside it
   CK(hipEventRecord(e0));
   for (int i = 0; i < reps; ++i) gemm_bf16x3<<<grid, NT>>>(da, db, dc, M, N, K);
   CK(hipEventRecord(e1));
