@@ -180,8 +180,8 @@ def test_fig2b_harness(dev):
         assert out['test_time'] > 0 and out['test_f1'] > 0.5
 
 
-@pytest.mark.parametrize("unsup", [True, "only"])
-def test_engine_trainer_step_with_unsup_term_matches_oracle(dev, unsup):
+@pytest.mark.parametrize("unsup,aggregator", [(True, "mean"), ("only", "mean"), (True, "gcn")])
+def test_engine_trainer_step_with_unsup_term_matches_oracle(dev, unsup, aggregator):
     """f-2 on the engine: loss = CE + unsupervised term (three forwards over one sampled batch,
     trainers/node_level_graphsage_trainers.py:41 + base_trainers.py:170-181) or the unsupervised
     term alone (:104-117; BASELINE.json configs[4]), gradients and the Adam step against the CPU
@@ -192,8 +192,8 @@ def test_engine_trainer_step_with_unsup_term_matches_oracle(dev, unsup):
     from graphsage_amd.samplers.uniform_loader import device_graph
     data = _dataset()[0]
     B, fan, lr, seed = 48, [5, 4], 1e-2, 17
-    layers = make_layers([24, 16, 5], "mean", 9)
-    model = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
+    layers = make_layers([24, 16, 5], aggregator, 9)
+    model = GraphSAGE(24, 16, aggregator, 2, 5).to(dev)
     load_layers(model, layers)
     graph = device_graph(data)
     engine = SageTrainEngine(model, NeighborSampler(data, fan, seed=seed), graph.features(data),
@@ -213,19 +213,20 @@ def test_engine_trainer_step_with_unsup_term_matches_oracle(dev, unsup):
         assert engine.neg_id[:nb].cpu().numpy().tolist() == neg.tolist()
         leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
         ei = torch.from_numpy(np.stack([src, dst]))
-        outs = [sage_ref.graphsage_forward(data.x[torch.from_numpy(ids)], ei, leaf)[:B] for ids in (node, pos, neg)]
+        outs = [sage_ref.graphsage_forward(data.x[torch.from_numpy(ids)], ei, leaf, aggregator)[:B]
+                for ids in (node, pos, neg)]
         want = sage_ref.unsup_loss(*outs)
         if unsup is True:
             want = want + F.cross_entropy(outs[0], data.y[torch.from_numpy(node[:B])])
         want.backward()
         torch.testing.assert_close(loss.cpu(), want.detach().view(1), rtol=1e-5, atol=1e-6)
         for m, lf in zip(model.layers, leaf):
-            torch.testing.assert_close(engine.gviews[m.lin_l.weight].cpu(), lf["lin_l"].grad, rtol=1e-3, atol=1e-6)
-            torch.testing.assert_close(engine.gviews[m.lin_r.weight].cpu(), lf["lin_r"].grad, rtol=1e-3, atol=1e-6)
+            for k in lf:      # lin_l, lin_r (gcn: lin_l only)
+                torch.testing.assert_close(engine.gviews[getattr(m, k).weight].cpu(), lf[k].grad, rtol=1e-3, atol=1e-6)
         for p, lf, st in zip(params, leaf, state):
             for k in p:
                 p[k], m1, v1 = sage_ref.adam_ref(p[k], lf[k].grad, st[k][0], st[k][1], step, lr)
                 st[k] = (m1, v1)
         for m, p in zip(model.layers, params):
-            torch.testing.assert_close(m.lin_l.weight.detach().cpu(), p["lin_l"], rtol=1e-4, atol=1e-6)
-            torch.testing.assert_close(m.lin_r.weight.detach().cpu(), p["lin_r"], rtol=1e-4, atol=1e-6)
+            for k in p:
+                torch.testing.assert_close(getattr(m, k).weight.detach().cpu(), p[k], rtol=1e-4, atol=1e-6)
