@@ -194,6 +194,7 @@ def main():
     N, E, Fdim, C, n_train = SHAPES[args.workload]
     B, K = args.batch_size, list(args.fanout)
     t_setup = time.perf_counter()
+    gemm_mode = "bf16x3" if os.environ.get("SAGE_GEMM_X3", "")[:1] == "1" else "f32"
     data = reddit_like_device(N, E, Fdim, C, seed=0, device=dev)   # identical on every rank
     graph = device_graph(data)
     feats, labels = graph.features(data), graph.labels(data)
@@ -339,27 +340,41 @@ def main():
         # Informational only (never `value`): the same step with overlap_gather — layer-0 gather of
         # batch i+1 on the side stream beside the forward GEMM of batch i — measured right after
         # the headline run on a second engine (DESIGN.md 4b says why it is not the default).
-        variant = None
+        def run_variant(overlap, x3):
+            import copy
+            if x3:
+                os.environ["SAGE_GEMM_X3"] = "1"      # read by the library at every call
+            try:
+                model2 = copy.deepcopy(model)
+                eng2 = SageTrainEngine(model2, NeighborSampler.from_graph(graph, K, seed=0), feats, labels, B,
+                                       lr=args.lr, overlap_gather=overlap)
+                for d in range(eng2.depth):
+                    eng2.prefetch(seeds_of(d), counter_of(d))
+                nv = min(args.steps, 200)
+                for s2 in range(args.warmup):
+                    eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
+                torch.cuda.synchronize()
+                tv = time.perf_counter()
+                for s2 in range(args.warmup, args.warmup + nv):
+                    eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
+                torch.cuda.synchronize()
+                tv = time.perf_counter() - tv
+                eng2.flush()
+                torch.cuda.synchronize()
+            finally:
+                if x3:
+                    del os.environ["SAGE_GEMM_X3"]
+            return {"ms_per_step": round(tv / nv * 1e3, 4), "value": round(B * nv / tv, 1),
+                    "unit": "seed nodes/s", "steps": nv}
+        variant = variant_x3 = None
         if world == 1 and not args.overlap_gather and not use_graph and not args.no_variant \
                 and args.variant == "fig2a":
-            import copy
-            model2 = copy.deepcopy(model)
-            eng2 = SageTrainEngine(model2, NeighborSampler.from_graph(graph, K, seed=0), feats, labels, B,
-                                   lr=args.lr, overlap_gather=True)
-            for d in range(eng2.depth):
-                eng2.prefetch(seeds_of(d), counter_of(d))
-            nv = min(args.steps, 200)
-            for s2 in range(args.warmup):
-                eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
-            torch.cuda.synchronize()
-            tv = time.perf_counter()
-            for s2 in range(args.warmup, args.warmup + nv):
-                eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
-            torch.cuda.synchronize()
-            tv = time.perf_counter() - tv
-            variant = {"schedule": "overlap_gather", "ms_per_step": round(tv / nv * 1e3, 4),
-                       "value": round(B * nv / tv, 1), "unit": "seed nodes/s", "steps": nv}
-            del eng2, model2
+            variant = dict(schedule="overlap_gather", **run_variant(True, False))
+            # Informational only as well: the headline schedule with the forward contraction in the
+            # opt-in bf16x3 mode (fp32 operands as three bf16 terms on the bf16 MFMA, fp32
+            # accumulation) — not the default, so never `value`
+            if gemm_mode == "f32":
+                variant_x3 = dict(gemm="bf16x3 forward (SAGE_GEMM_X3=1)", **run_variant(False, True))
         cpu = None
         if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a":   # the oracle times fig2a's step
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
@@ -382,6 +397,7 @@ def main():
                                        args.variant, "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},
             "roofline": roofline, "cpu_baseline": cpu, "variant_overlap_gather": variant,
+            "variant_gemm_bf16x3": variant_x3, "gemm_mode": gemm_mode,
             "final_loss": round(loss, 5), "setup_s": round(setup_s, 1), "settle_steps": base,
             "avg_nodes_per_batch": float(st[ops.ST_NODES]) / args.steps,
             "avg_edges_per_batch": float(st[ops.ST_EDGES]) / args.steps,

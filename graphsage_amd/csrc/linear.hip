@@ -205,6 +205,25 @@ struct TileLoader {
   }
 };
 
+// ---- bf16x3 mode (opt-in, SAGE_GEMM_X3=1): an fp32 value as three bf16 terms ------------
+// hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), all round-to-nearest: the residuals
+// are exact in fp32 and hi + mid + lo == x (24 significand bits in three 8-bit pieces), so
+// a.b = sum of nine exact bf16 x bf16 products; the kernel accumulates the six that are not below
+// 2^-26 of the product.  Two values per call, packed as the MFMA wants them (even k low half).
+__device__ inline unsigned cvt_pk_bf16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline void split_bf16x3(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk_bf16(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk_bf16(r0, r1);
+  const float q0 = r0 - __uint_as_float(mid << 16), q1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk_bf16(q0, q1);
+}
+constexpr int kX3RowBytes = 2 * BK + 16;   // one LDS row: BK bf16 + 16 B padding (20 dwords: conflict-free b128 reads)
+
 // Forward operand (contraction dim contiguous) with up to TWO K-segments behind one pipeline:
 // the K-loop runs over "unified" steps 0 .. steps0+steps1-1, the first steps0 of them in segment
 // 0, so the loads of segment 1 are already in flight while the last steps of segment 0 multiply
@@ -327,6 +346,37 @@ struct DualLoader {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) dst[j] = e[j];
       }
+    }
+  }
+
+  // bf16x3 mode: the same tile as three bf16 planes [mn][BK] (plane p at lds + p * plane_bytes)
+  template <int SET>
+  __device__ inline void store_x3(int step, unsigned char* lds, int plane_bytes) const {
+    static_assert(VEC == 4, "bf16x3 staging takes 16-byte vectors");
+    typedef unsigned u2v __attribute__((ext_vector_type(2)));
+    const bool s1 = step >= steps0;
+    const int k0a = kbeg0 + step * BK, k0b = kbeg1 + (step - steps0) * BK;
+    const int k0 = s1 ? k0b : k0a;
+    const int kea = kend0, keb = kend1;
+    const int ke = s1 ? keb : kea;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      VT x;
+      if constexpr (SET == 0) x = va[p];
+      else x = vb[p];
+      float e[4] = {x.x, x.y, x.z, x.w};
+      const int c0 = k0 + tcol(p);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c0 + j >= ke) e[j] = 0.f;
+      }
+      unsigned h0, m0, l0, h1, m1, l1;
+      split_bf16x3(e[0], e[1], h0, m0, l0);
+      split_bf16x3(e[2], e[3], h1, m1, l1);
+      unsigned char* dst = lds + trow(p) * kX3RowBytes + tcol(p) * 2;
+      *reinterpret_cast<u2v*>(dst) = u2v{h0, h1};
+      *reinterpret_cast<u2v*>(dst + plane_bytes) = u2v{m0, m1};
+      *reinterpret_cast<u2v*>(dst + 2 * plane_bytes) = u2v{l0, l1};
     }
   }
 };
@@ -739,6 +789,144 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
   }  // tile pieces
 }
 
+// Forward in bf16x3 mode (opt-in): the fp32 operands are split into three bf16 terms while they
+// are staged into LDS and six cross products per k16 go through v_mfma_f32_32x32x16_bf16 into
+// fp32 accumulators.  Same operand handling as the stream-K forward above (two K-segments, row
+// maps, device-side row count, K / N tails, partial tiles added with fp32 atomics into a zeroed
+// or accumulated-into output); 64 x 128 tile, one LDS stage, three resident workgroups per CU,
+// loads two steps ahead.  scratch/bf16x3_gemm.hip is the stand-alone study of this kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
+  constexpr int BM = 64, BN = 128;
+  constexpr int PLANE = (BM + BN) * kX3RowBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
+  int64_t m_lim = g.m;
+  if (g.m_dev != nullptr) {
+    const int64_t v = *g.m_dev;
+    if (v < m_lim) m_lim = v;
+  }
+  int k_lim0 = g.seg[0].k;
+  if (g.k_dev != nullptr) {
+    const int64_t v = *g.k_dev;
+    if (v < k_lim0) k_lim0 = static_cast<int>(v);
+  }
+  const int k_lim1 = g.nseg > 1 ? g.seg[1].k : 0;
+  const int S0 = (k_lim0 + BK - 1) / BK;
+  const int S = S0 + (k_lim1 + BK - 1) / BK;
+  const int tiles_n = (g.n + BN - 1) / BN;
+  const int64_t total = (m_lim + BM - 1) / BM * tiles_n * S;
+  unsigned lb_ = blockIdx.x;
+  if (gridDim.x % 8 == 0) lb_ = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
+  int64_t it = total * lb_ / gridDim.x;
+  const int64_t end = total * (lb_ + 1) / gridDim.x;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+  const int offa = (wm0 + l31) * kX3RowBytes + half * 16;
+  const int offb0 = (BM + wn0 + l31) * kX3RowBytes + half * 16, offb1 = offb0 + 32 * kX3RowBytes;
+  typedef unsigned u4v __attribute__((ext_vector_type(4)));
+  auto frag = [&](const unsigned char* p) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(p));
+  };
+  Operand a1 = g.seg[0].a, b1 = g.seg[0].b;
+  if (g.nseg > 1) {
+    a1 = g.seg[1].a;
+    b1 = g.seg[1].b;
+  }
+  DualLoader<BM, 4> la;
+  DualLoader<BN, 4> lb;
+  using S0_ = std::integral_constant<int, 0>;
+  using S1_ = std::integral_constant<int, 1>;
+
+  while (it < end) {   // block-uniform
+    const int64_t tile = it / S;
+    const int u0 = static_cast<int>(it - tile * S);
+    const int64_t left = end - it;
+    const int u1 = left < S - u0 ? u0 + static_cast<int>(left) : S;
+    it += u1 - u0;
+    const int64_t m0 = tile / tiles_n * BM, n0 = tile % tiles_n * BN;
+    const int a_lo = u0 < S0 ? u0 : S0, a_hi = u1 < S0 ? u1 : S0;
+    const int b_lo = (u0 > S0 ? u0 : S0) - S0, b_hi = (u1 > S0 ? u1 : S0) - S0;
+    const int kb0 = a_hi > a_lo ? a_lo * BK : 0;
+    const int ke0 = a_hi > a_lo ? (a_hi * BK < k_lim0 ? a_hi * BK : k_lim0) : 0;
+    const int kb1 = b_hi > b_lo ? b_lo * BK : 0;
+    const int ke1 = b_hi > b_lo ? (b_hi * BK < k_lim1 ? b_hi * BK : k_lim1) : 0;
+    la.begin(g.seg[0].a, a1, m0, m_lim);
+    lb.begin(g.seg[0].b, b1, n0, g.n);
+    const int nsteps = la.range(kb0, ke0, kb1, ke1);
+    lb.range(kb0, ke0, kb1, ke1);
+
+    floatx16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+    auto mfmas = [&]() {
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        bf16x8 a[3], b0[3], b1_[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          a[p] = frag(lds + p * PLANE + offa + 32 * s);
+          b0[p] = frag(lds + p * PLANE + offb0 + 32 * s);
+          b1_[p] = frag(lds + p * PLANE + offb1 + 32 * s);
+        }
+        // (a term, b term) of the six products, smallest first: lo.hi hi.lo mid.mid mid.hi hi.mid hi.hi
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b0[PB[q]], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b1_[PB[q]], acc[1], 0, 0, 0);
+        }
+      }
+    };
+    // one step: LDS holds step t, register set HOLD holds step t+1, set FREE takes step t+2
+    // (requests past the last step are clamped by the loader; their LDS image is never read)
+    auto step = [&](auto hold, auto free_, int t) {
+      constexpr int HOLD = decltype(hold)::value, FREE = decltype(free_)::value;
+      la.template issue<FREE>(t + 2);
+      lb.template issue<FREE>(t + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas();
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      la.template store_x3<HOLD>(t + 1, lds, PLANE);
+      lb.template store_x3<HOLD>(t + 1, lds + BM * kX3RowBytes, PLANE);
+      __syncthreads();
+    };
+    if (nsteps > 0) {
+      la.template issue<0>(0);
+      lb.template issue<0>(0);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template issue<1>(1);
+      lb.template issue<1>(1);
+      __builtin_amdgcn_sched_barrier(0);
+      la.template store_x3<0>(0, lds, PLANE);
+      lb.template store_x3<0>(0, lds + BM * kX3RowBytes, PLANE);
+      __syncthreads();
+      int t = 0;
+      for (; t + 1 < nsteps; t += 2) {
+        step(S1_{}, S0_{}, t);
+        step(S0_{}, S1_{}, t + 1);
+      }
+      if (t < nsteps) step(S1_{}, S0_{}, t);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn0 + j * 32 + l31;
+      const int64_t row0 = m0 + wm0 + 4 * half;
+      float* base = g.out + row0 * g.ld_out + col;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2);
+        if (col < g.n && row0 + r < m_lim) atomicAdd(base + r * g.ld_out, acc[j][e]);
+      }
+    }
+  }
+}
+
 // CUs of the current device (0 if the query fails: callers then keep whole-tile grids)
 int num_cus() {
   static int cached[64] = {};
@@ -1019,6 +1207,22 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
   // every one takes the same number of K-steps, partial tiles are added with fp32 atomics into a
   // zeroed output.
   const int slots = 2 * num_cus();
+  // opt-in bf16x3 mode (see gemm_x3_kernel): fp32-accurate, not the bit pattern of an fp32 FMA
+  // chain; large contractions with 16-byte aligned operands only, everything else as before
+  {
+    const char* x3 = getenv("SAGE_GEMM_X3");
+    bool vec4 = true;
+    for (int sgi = 0; sgi < g.nseg; ++sgi) vec4 = vec4 && g.seg[sgi].a.vec == 4 && g.seg[sgi].b.vec == 4;
+    const int64_t steps = tiles * (cdiv(k1, BK) + cdiv(k2, BK));
+    if (x3 != nullptr && x3[0] == '1' && (epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && n > 64 && slots > 0 &&
+        vec4 && steps >= 6ll * slots) {
+      if (!accum) zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
+      SAGE_CHECK_LAUNCH("zero_rows_kernel");
+      gemm_x3_kernel<<<dim3(static_cast<unsigned>(slots / 2 * 3)), kThreads, 0, stream>>>(g);
+      SAGE_CHECK_LAUNCH("gemm_x3_kernel");
+      return SAGE_OK;
+    }
+  }
   if ((epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && n > 64 && slots > 0 && tiles > slots / 2 &&
       tiles * 10 < cdiv(tiles, slots) * slots * 9) {
     g.streamk = 1;

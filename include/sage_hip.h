@@ -239,6 +239,12 @@ int sage_coo_to_csr(const sage_i64* edge_src, const sage_i64* edge_dst, sage_i64
  * (k2 = 0: 'gcn' aggregator / root_weight=False / pool).  Exact fp32 arithmetic on the
  * matrix cores (v_mfma_f32_32x32x2_f32): each output is an fp32 fma chain over k.
  * Alignment: every pointer and row stride must be a multiple of 8 bytes.
+ * Opt-in mode, environment variable SAGE_GEMM_X3=1 (read at every call; off by default):
+ * large contractions (n > 64, 16-byte aligned operands, epilogue NONE / ACCUM) run on the
+ * bf16 MFMA with every fp32 operand split into three bf16 terms (x = hi + mid + lo exactly)
+ * and six cross products accumulated in fp32 — the error against an exact result is that of
+ * the fp32 path or smaller, the bits are not those of an fp32 fma chain, and an Inf operand
+ * gives NaN.  No counterpart in the reference.
  * ---------------------------------------------------------------------------------- */
 int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sage_i64* rows1, int k1,
                            const float* w1, sage_i64 ld_w1, const float* a2, sage_i64 ld_a2,

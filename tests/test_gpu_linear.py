@@ -63,6 +63,53 @@ def test_linear_concat_fwd_stream_k(dev, m, n, k1, k2, m_frac):
     assert bool((acc[m_live:] == 0).all())
 
 
+def _pad16(x, dev):
+    ld = (x.size(1) + 15) // 16 * 16
+    buf = torch.full((x.size(0), ld), float("nan"), device=dev)    # padding must never reach a result
+    buf[:, :x.size(1)] = x.to(dev)
+    return buf[:, :x.size(1)]
+
+
+@pytest.mark.parametrize("m,n,k1,k2,m_frac", [(13100, 256, 602, 602, 1.0), (26000, 200, 130, 70, 0.6),
+                                              (9000, 256, 256, 0, 1.0)])
+def test_linear_concat_fwd_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
+    """SAGE_GEMM_X3=1 (opt-in): the forward contraction on the bf16 MFMA with every fp32 operand
+    split into three bf16 terms.  Against a float64 reference it must be as accurate as the
+    exact-fp32 MFMA path on the same inputs (K / N tails, row map, device-side row count,
+    accumulate), and it must actually have run (its bits differ from the fp32 path's)."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m + n + k1)
+    N = 5000
+    a1, w1 = _rand((m, k1), g), _rand((n, k1), g, k1 ** -0.5)
+    want = a1.double() @ w1.double().t()
+    a2 = w2 = rows = None
+    if k2:
+        table, w2 = _rand((N, k2), g), _rand((n, k2), g, k2 ** -0.5)
+        rows = torch.randint(0, N, (m,), generator=g)
+        want = want + table[rows].double() @ w2.double().t()
+        a2, w2 = _pad16(table, dev), _pad16(w2, dev)
+    m_live = int(m * m_frac)
+    mdev = torch.tensor([m_live], device=dev) if m_frac < 1.0 else None
+    args = (_pad16(a1, dev), _pad16(w1, dev), a2, w2)
+    kw = dict(rows2=rows.to(dev) if k2 else None, m=m, m_dev=mdev)
+
+    def run(accumulate):
+        out = torch.zeros((m, n), device=dev) if accumulate else torch.full((m, n), 7.0, device=dev)
+        ops.linear_concat_fwd(*args, out=out, accumulate=accumulate, **kw)
+        return out
+    monkeypatch.delenv("SAGE_GEMM_X3", raising=False)
+    f32 = run(False)
+    monkeypatch.setenv("SAGE_GEMM_X3", "1")
+    x3, x3_acc = run(False), run(True)
+    monkeypatch.delenv("SAGE_GEMM_X3")
+    err_f32 = (f32[:m_live].double().cpu() - want[:m_live]).abs().max()
+    for out in (x3, x3_acc):
+        err = (out[:m_live].double().cpu() - want[:m_live]).abs().max()
+        assert float(err) <= 2.0 * float(err_f32) + 1e-7, (float(err), float(err_f32))
+    assert not torch.equal(x3, f32)
+    assert bool((x3_acc[m_live:] == 0).all())
+
+
 def test_linear_concat_rowmaps_bias_relu_devcount(dev):
     from graphsage_amd import ops
     g = torch.Generator().manual_seed(0)
