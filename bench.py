@@ -370,11 +370,11 @@ def main():
         if world == 1 and not args.overlap_gather and not use_graph and not args.no_variant \
                 and args.variant == "fig2a":
             variant = dict(schedule="overlap_gather", **run_variant(True, False))
-            # Informational only as well: the headline schedule with the forward contraction in the
+            # Informational only as well: the headline schedule with the big contractions in the
             # opt-in bf16x3 mode (fp32 operands as three bf16 terms on the bf16 MFMA, fp32
             # accumulation) — not the default, so never `value`
             if gemm_mode == "f32":
-                variant_x3 = dict(gemm="bf16x3 forward (SAGE_GEMM_X3=1)", **run_variant(False, True))
+                variant_x3 = dict(gemm="bf16x3 forward + weight-gradient contractions (SAGE_GEMM_X3=1)", **run_variant(False, True))
         cpu = None
         if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a":   # the oracle times fig2a's step
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()

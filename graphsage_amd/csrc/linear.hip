@@ -203,6 +203,12 @@ struct TileLoader {
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) store_pass<LDS_LD, SET, TAIL>(p, k0, lds);
   }
+
+  // bf16x3 mode, k-major operand: the tile as three bf16 planes [k][row_bytes] with this
+  // operand's columns starting at `lds` (plane q at lds + q * plane_bytes); rows of the
+  // contraction tail are zeroed.  Defined after split_bf16x3 below.
+  template <int SET>
+  __device__ inline void store_x3(int k0, unsigned char* lds, int row_bytes, int plane_bytes) const;
 };
 
 // ---- bf16x3 mode (opt-in, SAGE_GEMM_X3=1): an fp32 value as three bf16 terms ------------
@@ -223,6 +229,31 @@ __device__ inline void split_bf16x3(float x0, float x1, unsigned& hi, unsigned& 
   lo = cvt_pk_bf16(q0, q1);
 }
 constexpr int kX3RowBytes = 2 * BK + 16;   // one LDS row: BK bf16 + 16 B padding (20 dwords: conflict-free b128 reads)
+
+template <bool KC, int MN, int VEC>
+template <int SET>
+__device__ inline void TileLoader<KC, MN, VEC>::store_x3(int k0, unsigned char* lds, int row_bytes,
+                                                         int plane_bytes) const {
+  static_assert(!KC && VEC == 4, "k-major operand staged in 16-byte vectors");
+  typedef unsigned u2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const VT x = v[SET][p];
+    float e[4] = {x.x, x.y, x.z, x.w};
+    const bool row_ok = k0 + trow(p) < k_end;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!row_ok) e[j] = 0.f;
+    }
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_bf16x3(e[0], e[1], h0, m0, l0);
+    split_bf16x3(e[2], e[3], h1, m1, l1);
+    unsigned char* dst = lds + trow(p) * row_bytes + tcol(p) * 2;
+    *reinterpret_cast<u2v*>(dst) = u2v{h0, h1};
+    *reinterpret_cast<u2v*>(dst + plane_bytes) = u2v{m0, m1};
+    *reinterpret_cast<u2v*>(dst + 2 * plane_bytes) = u2v{l0, l1};
+  }
+}
 
 // Forward operand (contraction dim contiguous) with up to TWO K-segments behind one pipeline:
 // the K-loop runs over "unified" steps 0 .. steps0+steps1-1, the first steps0 of them in segment
@@ -927,6 +958,147 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
   }
 }
 
+// Weight gradients in bf16x3 mode (opt-in): dw[n][k] += sum_m dout[m][n] * a[rows(m)][k], both
+// operands with the contraction index as their ROW index.  The tiles are staged as they lie in
+// memory — three bf16 planes [k][64 + 128 columns] — and the MFMA fragments (8 consecutive k per
+// lane) come out of LDS through the transposing read ds_read_b64_tr_b16.  Same grid and
+// arguments as the fp32 d-weight launch (split-K over blockIdx.z, the two problems of a layer
+// over blockIdx.y, device-side contraction length, fp32 atomics into dw).
+// scratch/bf16x3_dweight.hip is the stand-alone study.
+constexpr int kX3DwRowBytes = 448;   // 192 bf16 columns + 64 B: 112 dwords = 48 (mod 64), so the 4 rows
+                                     // x 16 dwords of a half-wave's transposing read tile the 64 banks
+__global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
+  constexpr int BM = 64, BN = 128;
+  constexpr int PLANE = BK * kX3DwRowBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
+  int by = blockIdx.y;
+  const bool prob = g.batched && by >= g.ny0;
+  if (prob) by -= g.ny0;
+  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM, n0 = static_cast<int64_t>(by) * BN;
+  const int64_t m_lim = g.m;
+  const int64_t n_lim = prob ? g.n2 : g.n;
+  float* const out_p = prob ? g.out2 : g.out;
+  const int64_t ld_out_p = prob ? g.ld_out2 : g.ld_out;
+  // (g.seg[] indexed with constants only, field by field: see gemm_kernel)
+  Operand oa, ob;
+  oa.p = prob ? g.seg[1].a.p : g.seg[0].a.p;
+  oa.ld = prob ? g.seg[1].a.ld : g.seg[0].a.ld;
+  oa.rowmap = prob ? g.seg[1].a.rowmap : g.seg[0].a.rowmap;
+  oa.vec = 4;
+  ob.p = prob ? g.seg[1].b.p : g.seg[0].b.p;
+  ob.ld = prob ? g.seg[1].b.ld : g.seg[0].b.ld;
+  ob.rowmap = prob ? g.seg[1].b.rowmap : g.seg[0].b.rowmap;
+  ob.vec = 4;
+  int k_lim = prob ? g.seg[1].k : g.seg[0].k;
+  if (g.k_dev != nullptr) {
+    const int64_t v = *g.k_dev;
+    if (v < k_lim) k_lim = static_cast<int>(v);
+  }
+  int k_beg = 0, k_end = k_lim;
+  if (g.k_chunk > 0) {
+    k_beg = blockIdx.z * g.k_chunk;
+    k_end = k_beg + g.k_chunk < k_lim ? k_beg + g.k_chunk : k_lim;
+  }
+  if (m0 >= m_lim || k_beg >= k_end) return;   // block-uniform: EXEC stays full for the transposing reads
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+  // transposing read: lane 4q+p of a 16-lane group addresses row (k) q, columns 4p..4p+3 of a
+  // 4 x 16 block and receives column (lane & 15) of it, row q in element q
+  const int grp = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
+  const int tr_row = 8 * half + q;
+  const int tra = tr_row * kX3DwRowBytes + (wm0 + 16 * grp + p4) * 2;
+  const int trb0 = tr_row * kX3DwRowBytes + (BM + wn0 + 16 * grp + p4) * 2, trb1 = trb0 + 64;
+  typedef short s4v __attribute__((ext_vector_type(4)));
+  typedef short s8v __attribute__((ext_vector_type(8)));
+  typedef __attribute__((address_space(3))) s4v* LdsS4;
+  auto frag = [&](const unsigned char* base) -> bf16x8 {   // k = 8 half + 0..7 of one k16 block
+    const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LdsS4)(base));
+    const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LdsS4)(base + 4 * kX3DwRowBytes));
+    const s8v w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, w);
+  };
+
+  TileLoader<false, BM, 4> la;
+  TileLoader<false, BN, 4> lb;
+  la.begin(oa, m0, m_lim, k_beg, k_end);
+  lb.begin(ob, n0, n_lim, k_beg, k_end);
+  floatx16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+
+  auto mfmas = [&]() {
+#pragma unroll
+    for (int s = 0; s < BK / 16; ++s) {
+      bf16x8 a[3], b0[3], b1[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned char* pl = lds + p * PLANE + 16 * s * kX3DwRowBytes;
+        a[p] = frag(pl + tra);
+        b0[p] = frag(pl + trb0);
+        b1[p] = frag(pl + trb1);
+      }
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+      for (int qq = 0; qq < 6; ++qq) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[qq]], b0[PB[qq]], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[qq]], b1[PB[qq]], acc[1], 0, 0, 0);
+      }
+    }
+  };
+  using S0_ = std::integral_constant<int, 0>;
+  using S1_ = std::integral_constant<int, 1>;
+  // one step: LDS holds the tile at k0, set HOLD the one at k0 + BK, set FREE takes k0 + 2 BK
+  // (requests past k_end are clamped by the loader; their LDS image is zeros and never read)
+  auto step = [&](auto hold, auto free_, int k0) {
+    constexpr int HOLD = decltype(hold)::value, FREE = decltype(free_)::value;
+    la.template issue<FREE>(k0 + 2 * BK);
+    lb.template issue<FREE>(k0 + 2 * BK);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas();
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    la.template store_x3<HOLD>(k0 + BK, lds, kX3DwRowBytes, PLANE);
+    lb.template store_x3<HOLD>(k0 + BK, lds + BM * 2, kX3DwRowBytes, PLANE);
+    __syncthreads();
+  };
+  la.template issue<0>(k_beg);
+  lb.template issue<0>(k_beg);
+  __builtin_amdgcn_sched_barrier(0);
+  la.template issue<1>(k_beg + BK);
+  lb.template issue<1>(k_beg + BK);
+  __builtin_amdgcn_sched_barrier(0);
+  la.template store_x3<0>(k_beg, lds, kX3DwRowBytes, PLANE);
+  lb.template store_x3<0>(k_beg, lds + BM * 2, kX3DwRowBytes, PLANE);
+  __syncthreads();
+  int k0 = k_beg;
+  for (; k0 + BK < k_end; k0 += 2 * BK) {
+    step(S1_{}, S0_{}, k0);
+    step(S0_{}, S1_{}, k0 + BK);
+  }
+  if (k0 < k_end) step(S1_{}, S0_{}, k0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t col = n0 + wn0 + j * 32 + l31;
+    const int64_t row0 = m0 + wm0 + 4 * half;
+    float* base = out_p + row0 * ld_out_p + col;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int r = (e & 3) + 8 * (e >> 2);
+      if (col < n_lim && row0 + r < m_lim) atomicAdd(base + r * ld_out_p, acc[j][e]);
+    }
+  }
+}
+
+// opt-in bf16x3 mode: SAGE_GEMM_X3=1 in the environment (read at every call)
+bool x3_mode() {
+  const char* v = getenv("SAGE_GEMM_X3");
+  return v != nullptr && v[0] == '1';
+}
+
 // CUs of the current device (0 if the query fails: callers then keep whole-tile grids)
 int num_cus() {
   static int cached[64] = {};
@@ -1210,11 +1382,10 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
   // opt-in bf16x3 mode (see gemm_x3_kernel): fp32-accurate, not the bit pattern of an fp32 FMA
   // chain; large contractions with 16-byte aligned operands only, everything else as before
   {
-    const char* x3 = getenv("SAGE_GEMM_X3");
     bool vec4 = true;
     for (int sgi = 0; sgi < g.nseg; ++sgi) vec4 = vec4 && g.seg[sgi].a.vec == 4 && g.seg[sgi].b.vec == 4;
     const int64_t steps = tiles * (cdiv(k1, BK) + cdiv(k2, BK));
-    if (x3 != nullptr && x3[0] == '1' && (epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && n > 64 && slots > 0 &&
+    if (x3_mode() && (epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && n > 64 && slots > 0 &&
         vec4 && steps >= 6ll * slots) {
       if (!accum) zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
       SAGE_CHECK_LAUNCH("zero_rows_kernel");
@@ -1352,6 +1523,13 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   if (splits < 1) splits = 1;
   g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
   splits = cdiv(m, g.k_chunk);
+  if (x3_mode() && dbias == nullptr && k > 64 && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && m >= 64 * BK) {
+    const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(cdiv(k, 128)),
+                    static_cast<unsigned>(splits));
+    gemm_x3_dw_kernel<<<grid, kThreads, 0, stream>>>(g);
+    SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel");
+    return SAGE_OK;
+  }
   return launch_gemm<false, false>(g, static_cast<int>(splits), stream, "gemm_kernel(dweight)");
 }
 
@@ -1417,5 +1595,12 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
   if (splits < 1) splits = 1;
   g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
   splits = cdiv(m, g.k_chunk);
+  if (x3_mode() && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && g.seg[1].b.vec == 4 && m >= 64 * BK) {
+    const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
+                    static_cast<unsigned>(splits));
+    gemm_x3_dw_kernel<<<grid, kThreads, 0, stream>>>(g);
+    SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel(pair)");
+    return SAGE_OK;
+  }
   return launch_gemm<false, false>(g, static_cast<int>(splits), stream, "gemm_kernel(dweight2)");
 }

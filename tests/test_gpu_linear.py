@@ -110,6 +110,46 @@ def test_linear_concat_fwd_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
     assert bool((x3_acc[m_live:] == 0).all())
 
 
+@pytest.mark.parametrize("m,n,k1,k2,m_frac", [(13100, 256, 602, 602, 0.95), (9000, 128, 300, 0, 1.0),
+                                              (4100, 200, 130, 258, 1.0)])
+def test_linear_dweight_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
+    """SAGE_GEMM_X3=1: the weight-gradient contractions (single and the layer's pair, row map,
+    device-side contraction length, column tails) on the bf16 MFMA through transposing LDS
+    reads: as accurate against float64 as the exact-fp32 path, and really taken."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m + n + k1)
+    N = 5000
+    m_live = int(m * m_frac)
+    dout, a1 = _rand((m, n), g, 1e-2), _rand((m, k1), g)
+    want1 = dout[:m_live].double().t() @ a1[:m_live].double()
+    mdev = torch.tensor([m_live], device=dev) if m_frac < 1.0 else None
+    dout_d, a1_d = _pad16(dout, dev), _pad16(a1, dev)
+    if k2:
+        table = _rand((N, k2), g)
+        rows = torch.randint(0, N, (m,), generator=g)
+        want2 = dout[:m_live].double().t() @ table[rows[:m_live]].double()
+        table_d, rows_d = _pad16(table, dev), rows.to(dev)
+
+    def run():
+        dw1 = torch.zeros((n, k1), device=dev)
+        if not k2:
+            ops.linear_dweight(dout_d, a1_d, m=m, m_dev=mdev, dw=dw1)
+            return dw1, None
+        dw2 = torch.zeros((n, k2), device=dev)
+        ops.linear_dweight2(dout_d, a1_d, dw1, table_d, dw2, m=m, m_dev=mdev, rows2=rows_d)
+        return dw1, dw2
+    monkeypatch.delenv("SAGE_GEMM_X3", raising=False)
+    f1, f2 = run()
+    monkeypatch.setenv("SAGE_GEMM_X3", "1")
+    x1, x2 = run()
+    monkeypatch.delenv("SAGE_GEMM_X3")
+    for got, ref, want in ((x1, f1, want1),) + (((x2, f2, want2),) if k2 else ()):
+        err = (got.double().cpu() - want).abs().max()
+        err_f32 = (ref.double().cpu() - want).abs().max()
+        assert float(err) <= 2.0 * float(err_f32) + 1e-8, (float(err), float(err_f32))
+        assert not torch.equal(got, ref)
+
+
 def test_linear_concat_rowmaps_bias_relu_devcount(dev):
     from graphsage_amd import ops
     g = torch.Generator().manual_seed(0)
