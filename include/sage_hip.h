@@ -244,7 +244,8 @@ int sage_coo_to_csr(const sage_i64* edge_src, const sage_i64* edge_dst, sage_i64
  * bf16 MFMA with every fp32 operand split into three bf16 terms (x = hi + mid + lo exactly)
  * and six cross products accumulated in fp32 — the error against an exact result is that of
  * the fp32 path or smaller, the bits are not those of an fp32 fma chain, and an Inf operand
- * gives NaN.  No counterpart in the reference.
+ * gives NaN.  The same switch covers the large weight-gradient contractions of
+ * sage_linear_dweight / sage_linear_dweight2 below.  No counterpart in the reference.
  * ---------------------------------------------------------------------------------- */
 int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sage_i64* rows1, int k1,
                            const float* w1, sage_i64 ld_w1, const float* a2, sage_i64 ld_a2,
