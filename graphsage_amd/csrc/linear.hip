@@ -7,7 +7,9 @@
 //
 // Arithmetic is exact fp32 on the MFMA pipe: v_mfma_f32_32x32x2_f32 (gfx950 has no
 // xf32/TF32 path).  Every output element is an fp32 fma chain over k, so results agree
-// with an fp32 reference to summation-order rounding.
+// with an fp32 reference to summation-order rounding.  (Opt-in, SAGE_GEMM_X3=1: the large forward
+// and weight-gradient contractions run on the bf16 MFMA with each fp32 operand split into three
+// bf16 terms — gemm_x3_kernel / gemm_x3_dw_kernel below; fp32-accurate, other bits.)
 //
 // One tile kernel serves the three contractions.  In "C[M][N] = sum_k A(m,k) B(k,n)" form:
 //   forward   : A(m,k) = a[rows(m)][k]   (k contiguous)   B(k,n) = w[n][k]   (k contiguous)
