@@ -71,12 +71,13 @@ def _pad16(x, dev):
 
 
 @pytest.mark.parametrize("m,n,k1,k2,m_frac", [(13100, 256, 602, 602, 1.0), (26000, 200, 130, 70, 0.6),
-                                              (9000, 256, 256, 0, 1.0)])
+                                              (9000, 256, 512, 0, 1.0)])
 def test_linear_concat_fwd_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
     """SAGE_GEMM_X3=1 (opt-in): the forward contraction on the bf16 MFMA with every fp32 operand
     split into three bf16 terms.  Against a float64 reference it must be as accurate as the
     exact-fp32 MFMA path on the same inputs (K / N tails, row map, device-side row count,
-    accumulate), and it must actually have run (its bits differ from the fp32 path's)."""
+    accumulate), and it must actually have run (its bits differ from the fp32 path's; the shapes
+    are above the mode's size threshold: tiles x K-steps >= 6 per resident workgroup)."""
     from graphsage_amd import ops
     g = torch.Generator().manual_seed(m + n + k1)
     N = 5000
