@@ -216,8 +216,9 @@ struct TileLoader {
 // ---- bf16x3 mode (opt-in, SAGE_GEMM_X3=1): an fp32 value as three bf16 terms ------------
 // hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), all round-to-nearest: the residuals
 // are exact in fp32 and hi + mid + lo == x (24 significand bits in three 8-bit pieces), so
-// a.b = sum of nine exact bf16 x bf16 products; the kernel accumulates the six that are not below
-// 2^-26 of the product.  Two values per call, packed as the MFMA wants them (even k low half).
+// a.b = sum of nine exact bf16 x bf16 products; the kernel accumulates six and drops mid.lo, lo.mid
+// and lo.lo: at most 2^-24 of the product (|mid| <= 2^-8 |x|, |lo| <= 2^-17 |x|), 2^-28 on average
+// (tests/test_x3_split_cpu.py).  Two values per call, packed as the MFMA wants them (even k low half).
 __device__ inline unsigned cvt_pk_bf16(float a, float b) {
   unsigned r;
   asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

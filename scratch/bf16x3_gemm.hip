@@ -1,7 +1,7 @@
 // Experiment: fp32-accurate GEMM C[M][N] = A[M][K] * B[N][K]^T on the bf16 MFMA.
 // Every fp32 operand is split (round-to-nearest) into three bf16 terms hi + mid + lo = x exactly;
 // six of the nine cross products are accumulated in fp32 (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo,
-// lo*hi): the three dropped ones are below 2^-26 of the product, under fp32's own rounding.
+// lo*hi): the three dropped ones are at most 2^-24 of the product (2^-28 on average): fp32's own rounding.
 // v_mfma_f32_32x32x16_bf16 runs at 16x the flops of v_mfma_f32_32x32x2_f32, so six of them per
 // k16 cost 3/8 of the fp32 MFMA time; the split costs 5.5 VALU ops per loaded element.
 // Build: hipcc -O3 --offload-arch=gfx950 scratch/bf16x3_gemm.hip -o scratch/bf16x3_gemm
