@@ -231,7 +231,11 @@ __device__ inline void split_bf16x3(float x0, float x1, unsigned& hi, unsigned& 
   const float q0 = r0 - __uint_as_float(mid << 16), q1 = r1 - __uint_as_float(mid & 0xffff0000u);
   lo = cvt_pk_bf16(q0, q1);
 }
-constexpr int kX3RowBytes = 2 * BK + 16;   // one LDS row: BK bf16 + 16 B padding (20 dwords: conflict-free b128 reads)
+// k-contiguous planes (forward): one LDS row = BK bf16 = 64 bytes, no padding; the four 16-byte
+// slots of row r are stored at slot ^ ((-((r & 15) >> 2)) & 3), which makes the b128 fragment
+// reads of v_mfma_f32_16x16x32_bf16 (lane = row r & 15, slot = lane >> 4) conflict-free
+constexpr int kX3RowBytes = 2 * BK;
+__device__ inline int x3_slot(int row, int slot) { return ((slot ^ (-((row & 15) >> 2))) & 3) << 4; }
 
 template <bool KC, int MN, int VEC>
 template <int SET>
@@ -407,7 +411,8 @@ struct DualLoader {
       unsigned h0, m0, l0, h1, m1, l1;
       split_bf16x3(e[0], e[1], h0, m0, l0);
       split_bf16x3(e[2], e[3], h1, m1, l1);
-      unsigned char* dst = lds + trow(p) * kX3RowBytes + tcol(p) * 2;
+      // (tile rows start at a multiple of 16 in the plane: MN and the operand's row offset are)
+      unsigned char* dst = lds + trow(p) * kX3RowBytes + x3_slot(trow(p), tcol(p) >> 3) + ((tcol(p) >> 2) & 1) * 8;
       *reinterpret_cast<u2v*>(dst) = u2v{h0, h1};
       *reinterpret_cast<u2v*>(dst + plane_bytes) = u2v{m0, m1};
       *reinterpret_cast<u2v*>(dst + 2 * plane_bytes) = u2v{l0, l1};
@@ -855,10 +860,11 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
   const int64_t end = total * (lb_ + 1) / gridDim.x;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
+  const int r16 = lane & 15, kg = lane >> 4;     // 16x16x32 operand: row r16, k = 8 kg .. 8 kg + 7
   const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
-  const int offa = (wm0 + l31) * kX3RowBytes + half * 16;
-  const int offb0 = (BM + wn0 + l31) * kX3RowBytes + half * 16, offb1 = offb0 + 32 * kX3RowBytes;
+  const int offa = (wm0 + r16) * kX3RowBytes + x3_slot(r16, kg);          // + 16 i rows
+  const int offb = (BM + wn0 + r16) * kX3RowBytes + x3_slot(r16, kg);     // + 16 j rows
+  typedef float floatx4 __attribute__((ext_vector_type(4)));
   typedef unsigned u4v __attribute__((ext_vector_type(4)));
   auto frag = [&](const unsigned char* p) -> bf16x8 {
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const u4v*>(p));
@@ -891,29 +897,37 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
     const int nsteps = la.range(kb0, ke0, kb1, ke1);
     lb.range(kb0, ke0, kb1, ke1);
 
-    floatx16 acc[2];
+    floatx4 acc[2][4];       // the wave's 32 x 64 tile as 2 x 4 blocks of 16 x 16
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
+    // v_mfma_f32_16x16x32_bf16 (one K-step of 32 per instruction) rather than 32x32x16: the same
+    // cycles per flop at lower power, and this kernel is power-limited (scratch/bf16x3_gemm_16.hip:
+    // 57.9 vs 61.8 us sustained)
     auto mfmas = [&]() {
+      // the A fragments stay, the B fragments of one 16-column block at a time (register budget:
+      // 168 VGPRs at three workgroups per CU)
+      bf16x8 a[2][3];
 #pragma unroll
-      for (int s = 0; s < BK / 16; ++s) {
-        bf16x8 a[3], b0[3], b1_[3];
+      for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-          a[p] = frag(lds + p * PLANE + offa + 32 * s);
-          b0[p] = frag(lds + p * PLANE + offb0 + 32 * s);
-          b1_[p] = frag(lds + p * PLANE + offb1 + 32 * s);
-        }
-        // (a term, b term) of the six products, smallest first: lo.hi hi.lo mid.mid mid.hi hi.mid hi.hi
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        for (int i = 0; i < 2; ++i) a[i][p] = frag(lds + p * PLANE + offa + i * 16 * kX3RowBytes);
+      // (a term, b term) of the six products, smallest first: lo.hi hi.lo mid.mid mid.hi hi.mid hi.hi
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b0[PB[q]], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]], b1_[PB[q]], acc[1], 0, 0, 0);
-        }
+      for (int j = 0; j < 4; ++j) {
+        bf16x8 b[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[p] = frag(lds + p * PLANE + offb + j * 16 * kX3RowBytes);
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA[q]], b[PB[q]], acc[i][j], 0, 0, 0);
       }
     };
     // one step: LDS holds step t, register set HOLD holds step t+1, set FREE takes step t+2
@@ -947,17 +961,19 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
       }
       if (t < nsteps) step(S1_{}, S0_{}, t);
     }
+    // C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn0 + j * 32 + l31;
-      const int64_t row0 = m0 + wm0 + 4 * half;
-      float* base = g.out + row0 * g.ld_out + col;
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = (e & 3) + 8 * (e >> 2);
-        if (col < g.n && row0 + r < m_lim) atomicAdd(base + r * g.ld_out, acc[j][e]);
+      for (int j = 0; j < 4; ++j) {
+        const int64_t col = n0 + wn0 + j * 16 + r16;
+        const int64_t row0 = m0 + wm0 + i * 16 + 4 * kg;
+        float* base = g.out + row0 * g.ld_out + col;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (col < g.n && row0 + e < m_lim) atomicAdd(base + e * g.ld_out, acc[i][j][e]);
+        }
       }
-    }
   }
 }
 
