@@ -207,10 +207,10 @@ struct TileLoader {
   }
 
   // bf16x3 mode, k-major operand: the tile as three bf16 planes [k][row_bytes] with this
-  // operand's columns starting at `lds` (plane q at lds + q * plane_bytes); rows of the
-  // contraction tail are zeroed.  Defined after split_bf16x3 below.
+  // operand's columns starting at column col0 of the plane (plane q at lds + q * plane_bytes);
+  // rows of the contraction tail are zeroed.  Defined after split_bf16x3 below.
   template <int SET>
-  __device__ inline void store_x3(int k0, unsigned char* lds, int row_bytes, int plane_bytes) const;
+  __device__ inline void store_x3(int k0, unsigned char* lds, int col0, int row_bytes, int plane_bytes) const;
 };
 
 // ---- bf16x3 mode (opt-in, SAGE_GEMM_X3=1): an fp32 value as three bf16 terms ------------
@@ -237,9 +237,17 @@ __device__ inline void split_bf16x3(float x0, float x1, unsigned& hi, unsigned& 
 constexpr int kX3RowBytes = 2 * BK;
 __device__ inline int x3_slot(int row, int slot) { return ((slot ^ (-((row & 15) >> 2))) & 3) << 4; }
 
+// k-major planes (weight gradients): byte offset of column `col` (a multiple of 4) in row k.  The
+// 32-byte blocks (16 columns) of rows with (k >> 3) odd are swapped in pairs, so that the two
+// 16-lane groups of a half-wave — k = 8 kg .. for kg even and odd, same 16 columns — hit
+// different banks in the transposing fragment reads of the 16x16x32 MFMA.
+__device__ inline int x3_dw_offset(int k, int col, int row_bytes) {
+  return k * row_bytes + (((col >> 4) ^ ((k >> 3) & 1)) << 5) + ((col * 2) & 31);
+}
+
 template <bool KC, int MN, int VEC>
 template <int SET>
-__device__ inline void TileLoader<KC, MN, VEC>::store_x3(int k0, unsigned char* lds, int row_bytes,
+__device__ inline void TileLoader<KC, MN, VEC>::store_x3(int k0, unsigned char* lds, int col0, int row_bytes,
                                                          int plane_bytes) const {
   static_assert(!KC && VEC == 4, "k-major operand staged in 16-byte vectors");
   typedef unsigned u2v __attribute__((ext_vector_type(2)));
@@ -255,7 +263,7 @@ __device__ inline void TileLoader<KC, MN, VEC>::store_x3(int k0, unsigned char* 
     unsigned h0, m0, l0, h1, m1, l1;
     split_bf16x3(e[0], e[1], h0, m0, l0);
     split_bf16x3(e[2], e[3], h1, m1, l1);
-    unsigned char* dst = lds + trow(p) * row_bytes + tcol(p) * 2;
+    unsigned char* dst = lds + x3_dw_offset(trow(p), col0 + tcol(p), row_bytes);
     *reinterpret_cast<u2v*>(dst) = u2v{h0, h1};
     *reinterpret_cast<u2v*>(dst + plane_bytes) = u2v{m0, m1};
     *reinterpret_cast<u2v*>(dst + 2 * plane_bytes) = u2v{l0, l1};
@@ -1021,18 +1029,19 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   if (m0 >= m_lim || k_beg >= k_end) return;   // block-uniform: EXEC stays full for the transposing reads
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l31 = lane & 31, half = lane >> 5;
+  const int r16 = lane & 15, kg = lane >> 4;     // 16x16x32 operand: column r16, k = 8 kg .. 8 kg + 7
   const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
   // transposing read: lane 4q+p of a 16-lane group addresses row (k) q, columns 4p..4p+3 of a
-  // 4 x 16 block and receives column (lane & 15) of it, row q in element q
-  const int grp = (lane >> 4) & 1, q = (lane & 15) >> 2, p4 = (lane & 3) * 4;
-  const int tr_row = 8 * half + q;
-  const int tra = tr_row * kX3DwRowBytes + (wm0 + 16 * grp + p4) * 2;
-  const int trb0 = tr_row * kX3DwRowBytes + (BM + wn0 + 16 * grp + p4) * 2, trb1 = trb0 + 64;
+  // 4 x 16 block and receives column (lane & 15) of it, row q in element q.  Group kg reads rows
+  // 8 kg + q (and + 4 in a second read) of the 16 columns of block cb.
+  const int q = r16 >> 2, p4 = (lane & 3) * 4;
+  const int tr_row = 8 * kg + q;
+  typedef float floatx4 __attribute__((ext_vector_type(4)));
   typedef short s4v __attribute__((ext_vector_type(4)));
   typedef short s8v __attribute__((ext_vector_type(8)));
   typedef __attribute__((address_space(3))) s4v* LdsS4;
-  auto frag = [&](const unsigned char* base) -> bf16x8 {   // k = 8 half + 0..7 of one k16 block
+  auto frag = [&](const unsigned char* plane, int col) -> bf16x8 {   // col: first of the block's 16 columns
+    const unsigned char* base = plane + x3_dw_offset(tr_row, col + p4, kX3DwRowBytes);   // (tr_row + 4) >> 3 == tr_row >> 3
     const s4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LdsS4)(base));
     const s4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((LdsS4)(base + 4 * kX3DwRowBytes));
     const s8v w = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1043,29 +1052,33 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   TileLoader<false, BN, 4> lb;
   la.begin(oa, m0, m_lim, k_beg, k_end);
   lb.begin(ob, n0, n_lim, k_beg, k_end);
-  floatx16 acc[2];
+  floatx4 acc[2][4];       // the wave's 32 x 64 tile as 2 x 4 blocks of 16 x 16
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
 
+  // v_mfma_f32_16x16x32_bf16, one K-step of 32 per instruction (see gemm_x3_kernel); the A
+  // fragments stay, the B fragments of one 16-column block at a time
   auto mfmas = [&]() {
+    bf16x8 a[2][3];
 #pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      bf16x8 a[3], b0[3], b1[3];
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const unsigned char* pl = lds + p * PLANE + 16 * s * kX3DwRowBytes;
-        a[p] = frag(pl + tra);
-        b0[p] = frag(pl + trb0);
-        b1[p] = frag(pl + trb1);
-      }
-      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+      for (int i = 0; i < 2; ++i) a[i][p] = frag(lds + p * PLANE, wm0 + 16 * i);
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
 #pragma unroll
-      for (int qq = 0; qq < 6; ++qq) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[qq]], b0[PB[qq]], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[qq]], b1[PB[qq]], acc[1], 0, 0, 0);
-      }
+    for (int j = 0; j < 4; ++j) {
+      bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = frag(lds + p * PLANE, BM + wn0 + 16 * j);
+#pragma unroll
+      for (int qq = 0; qq < 6; ++qq)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA[qq]], b[PB[qq]], acc[i][j], 0, 0, 0);
     }
   };
   using S0_ = std::integral_constant<int, 0>;
@@ -1080,8 +1093,8 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
     mfmas();
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
-    la.template store_x3<HOLD>(k0 + BK, lds, kX3DwRowBytes, PLANE);
-    lb.template store_x3<HOLD>(k0 + BK, lds + BM * 2, kX3DwRowBytes, PLANE);
+    la.template store_x3<HOLD>(k0 + BK, lds, 0, kX3DwRowBytes, PLANE);
+    lb.template store_x3<HOLD>(k0 + BK, lds, BM, kX3DwRowBytes, PLANE);
     __syncthreads();
   };
   la.template issue<0>(k_beg);
@@ -1090,8 +1103,8 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   la.template issue<1>(k_beg + BK);
   lb.template issue<1>(k_beg + BK);
   __builtin_amdgcn_sched_barrier(0);
-  la.template store_x3<0>(k_beg, lds, kX3DwRowBytes, PLANE);
-  lb.template store_x3<0>(k_beg, lds + BM * 2, kX3DwRowBytes, PLANE);
+  la.template store_x3<0>(k_beg, lds, 0, kX3DwRowBytes, PLANE);
+  lb.template store_x3<0>(k_beg, lds, BM, kX3DwRowBytes, PLANE);
   __syncthreads();
   int k0 = k_beg;
   for (; k0 + BK < k_end; k0 += 2 * BK) {
@@ -1099,17 +1112,19 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
     step(S0_{}, S1_{}, k0 + BK);
   }
   if (k0 < k_end) step(S1_{}, S0_{}, k0);
+  // C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t col = n0 + wn0 + j * 32 + l31;
-    const int64_t row0 = m0 + wm0 + 4 * half;
-    float* base = out_p + row0 * ld_out_p + col;
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = (e & 3) + 8 * (e >> 2);
-      if (col < n_lim && row0 + r < m_lim) atomicAdd(base + r * ld_out_p, acc[j][e]);
+    for (int j = 0; j < 4; ++j) {
+      const int64_t col = n0 + wn0 + j * 16 + r16;
+      const int64_t row0 = m0 + wm0 + i * 16 + 4 * kg;
+      float* base = out_p + row0 * ld_out_p + col;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (col < n_lim && row0 + e < m_lim) atomicAdd(base + e * ld_out_p, acc[i][j][e]);
+      }
     }
-  }
 }
 
 // opt-in bf16x3 mode: SAGE_GEMM_X3=1 in the environment (read at every call)
