@@ -16,6 +16,8 @@
 //     cleared.
 #include <rocprim/device/device_scan.hpp>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace sage {
@@ -323,6 +325,40 @@ size_t scan_temp_bytes(size_t n) {
 
 using namespace sage;
 
+// Workspace of sage_sample_fanout_static: one array per GPU, resident until the process ends.
+// In host code the NAME is a stand-in, not a device address: static_scratch_ptr() resolves the
+// address on the current device once and every launch below receives that pointer.
+static __device__ __align__(256) unsigned char scratch[SAGE_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+// Address of `scratch` on the device that is current for the calling thread (each GPU holds its
+// own copy at its own address); 0 and an error message on failure.
+void* static_scratch_ptr() {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    sage::set_error("sage_sample_fanout_static: hipGetDevice: %s (device %d)",
+                    hipGetErrorString(e), dev);
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || p == nullptr) {
+      sage::set_error("sage_sample_fanout_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+      return nullptr;
+    }
+    g_scratch_ptr[dev] = p;
+  }
+  return g_scratch_ptr[dev];
+}
+}  // namespace
+
 extern "C" size_t sage_sample_workspace_bytes(sage_i64 node_cap, sage_i64 edge_cap) {
   if (node_cap < 0 || edge_cap < 0) return 0;
   size_t n = static_cast<size_t>(node_cap > edge_cap ? node_cap : edge_cap) + 2;
@@ -514,4 +550,30 @@ extern "C" int sage_state_accumulate(const sage_i64* state, sage_i64* sum, void*
   state_accumulate_kernel<<<1, SAGE_STATE_WORDS, 0, static_cast<hipStream_t>(stream)>>>(state, sum);
   SAGE_CHECK_LAUNCH("state_accumulate_kernel");
   return SAGE_OK;
+}
+
+extern "C" int sage_sample_fanout_static(const sage_i64* colptr, const sage_i64* row,
+                                         sage_i64 num_nodes, const sage_i64* seeds, int num_seeds,
+                                         const int* fanout_host, int hops, uint64_t rng_seed,
+                                         uint64_t rng_counter, uint64_t* relabel_table,
+                                         uint32_t stamp, sage_i64 node_cap, sage_i64 edge_cap,
+                                         sage_i64* node, sage_i64* src, sage_i64* dst, sage_i64* eid,
+                                         sage_i64* seg_ptr, sage_i64* state, void* stream) {
+  SAGE_REQUIRE(node_cap >= 0 && edge_cap >= 0 && node_cap < (1ll << 31) && edge_cap < (1ll << 31),
+               SAGE_ELIMIT, "sage_sample_fanout_static: node_cap=%lld / edge_cap=%lld out of range",
+               (long long)node_cap, (long long)edge_cap);
+  const size_t need = sage_sample_workspace_bytes(node_cap, edge_cap);
+  SAGE_REQUIRE(need <= static_cast<size_t>(SAGE_STATIC_SCRATCH_BYTES), SAGE_ELIMIT,
+               "sage_sample_fanout_static: node_cap=%lld / edge_cap=%lld need %zu bytes of scratch, the "
+               "static array holds %zu: use sage_sample_fanout with a caller workspace",
+               (long long)node_cap, (long long)edge_cap, need,
+               static_cast<size_t>(SAGE_STATIC_SCRATCH_BYTES));
+  void* ws = static_scratch_ptr();
+  if (ws == nullptr) return SAGE_ELAUNCH;
+  // every word of the workspace that a kernel reads is written earlier in the same call (hop
+  // info, counts, offsets, flags, ranks, scan state), so nothing has to be cleared between calls
+  return sage_sample_fanout_ctrl(colptr, row, num_nodes, seeds, num_seeds, fanout_host, hops,
+                                 rng_seed, rng_counter, relabel_table, stamp, nullptr, node_cap,
+                                 edge_cap, node, src, dst, eid, seg_ptr, state, ws,
+                                 static_cast<size_t>(SAGE_STATIC_SCRATCH_BYTES), stream);
 }

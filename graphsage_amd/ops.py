@@ -180,6 +180,33 @@ def sample_fanout(colptr, row, seeds, fanout, rng_seed, rng_counter, table, stam
     _lib.check(rc, "sage_sample_fanout")
 
 
+STATIC_SCRATCH_BYTES = 8 << 20
+
+
+def sample_fanout_static(colptr, row, seeds, fanout, rng_seed, rng_counter, table, stamp, buf):
+    """sample_fanout through sage_sample_fanout_static: the same results with the library's own
+    static device array as the workspace (buf.ws is not used) — the entry point for callers that
+    cannot allocate.  Capacities beyond STATIC_SCRATCH_BYTES of workspace raise RuntimeError."""
+    lib = _lib.load()
+    num_nodes = colptr.numel() - 1
+    if buf.num_nodes != num_nodes or table.numel() != num_nodes:
+        raise RuntimeError("sample_fanout_static: buffers/table were sized for another graph")
+    hops = len(fanout)
+    fan = (ctypes.c_int * hops)(*[int(k) for k in fanout])
+    B = seeds.numel()
+    if B > buf.node_cap:
+        raise RuntimeError("sample_fanout_static: num_seeds exceeds the node capacity")
+    rc = lib.sage_sample_fanout_static(
+        _vec(colptr, torch.int64, "colptr"), _vec(row, torch.int64, "row"), num_nodes,
+        _vec(seeds, torch.int64, "seeds"), B, fan, hops,
+        int(rng_seed) & 0xFFFFFFFFFFFFFFFF, int(rng_counter) & 0xFFFFFFFFFFFFFFFF,
+        _p(table, torch.int64, "relabel_table"), int(stamp), buf.node_cap, buf.edge_cap,
+        _p(buf.node, torch.int64, "node"), _p(buf.src, torch.int64, "src"),
+        _p(buf.dst, torch.int64, "dst"), _p(buf.eid, torch.int64, "eid"),
+        _p(buf.seg_ptr, torch.int64, "seg_ptr"), _p(buf.state, torch.int64, "state"), _stream())
+    _lib.check(rc, "sage_sample_fanout_static")
+
+
 def state_accumulate(state, total):
     """total += state (both int64[STATE_WORDS] on the device)."""
     lib = _lib.load()
