@@ -61,6 +61,9 @@ struct GemmArgs {
   const float* bias;
   int epilogue;            // SAGE_EPI_* flags
   int atomic_out;          // 1: atomicAdd into out (split-K / accumulate)
+  int rmw_out;             // 1: out += product by plain load-add-store (whole tiles: one owner per element)
+  int whole;               // bf16x3 forward: workgroups take WHOLE tiles (no partial pieces, no atomics),
+                           // so the bias / relu / rmw epilogues apply
   int k_chunk;             // split-K: contraction elements per blockIdx.z (multiple of BK)
   // stream-K (forward only): a 1-D grid of gridDim.x workgroups shares the K-steps of ALL tiles
   // evenly; a workgroup walks a contiguous range of (tile, K-step) pairs, stores a tile it
@@ -812,7 +815,10 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
           const int r = (e & 3) + 8 * (e >> 2);
           float v = acc[i][j][e] + bv[j];
           if (relu) v = fmaxf(v, 0.f);
-          if (col < n_lim && row0 + r < m_lim) base[r * ld_out_p] = v;
+          if (col < n_lim && row0 + r < m_lim) {
+            if (g.rmw_out) v += base[r * ld_out_p];
+            base[r * ld_out_p] = v;
+          }
         }
       }
     }
@@ -865,7 +871,13 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
   unsigned lb_ = blockIdx.x;
   if (gridDim.x % 8 == 0) lb_ = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
   int64_t it = total * lb_ / gridDim.x;
-  const int64_t end = total * (lb_ + 1) / gridDim.x;
+  int64_t end_ = total * (lb_ + 1) / gridDim.x;
+  if (g.whole) {   // whole tiles only: the range boundaries are tile boundaries
+    const int64_t ntiles = total / S;
+    it = ntiles * lb_ / gridDim.x * S;
+    end_ = ntiles * (lb_ + 1) / gridDim.x * S;
+  }
+  const int64_t end = end_;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;     // 16x16x32 operand: row r16, k = 8 kg .. 8 kg + 7
@@ -977,9 +989,23 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
         const int64_t col = n0 + wn0 + j * 16 + r16;
         const int64_t row0 = m0 + wm0 + i * 16 + 4 * kg;
         float* base = g.out + row0 * g.ld_out + col;
+        if (!g.whole) {   // block-uniform
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (col < g.n && row0 + e < m_lim) atomicAdd(base + e * g.ld_out, acc[i][j][e]);
+          for (int e = 0; e < 4; ++e) {
+            if (col < g.n && row0 + e < m_lim) atomicAdd(base + e * g.ld_out, acc[i][j][e]);
+          }
+        } else {
+          const float bv = ((g.epilogue & SAGE_EPI_BIAS) && col < g.n) ? g.bias[col] : 0.f;
+          const bool relu = (g.epilogue & SAGE_EPI_RELU) != 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (col < g.n && row0 + e < m_lim) {
+              float v = acc[i][j][e] + bv;
+              if (relu) v = fmaxf(v, 0.f);
+              if (g.rmw_out) v += base[e * g.ld_out];
+              base[e * g.ld_out] = v;
+            }
+          }
         }
       }
   }
@@ -1127,10 +1153,11 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
     }
 }
 
-// opt-in bf16x3 mode: SAGE_GEMM_X3=1 in the environment (read at every call)
+// bf16x3 mode is the default for the large contractions; SAGE_GEMM_X3=0 in the environment
+// (read at every call) keeps them on the exact-fp32 MFMA
 bool x3_mode() {
   const char* v = getenv("SAGE_GEMM_X3");
-  return v != nullptr && v[0] == '1';
+  return v == nullptr || v[0] != '0';
 }
 
 // CUs of the current device (0 if the query fails: callers then keep whole-tile grids)
@@ -1350,6 +1377,32 @@ skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, SkinnyDwP
   }
 }
 
+// dbias[n] += sum over a chunk of rows of dout[m][n]: thread per column, coalesced along n
+__global__ void __launch_bounds__(kThreads)
+colsum_kernel(const float* __restrict__ dout, int64_t ld, int64_t m, const int64_t* __restrict__ m_dev,
+              int n, int m_chunk, float* __restrict__ dbias) {
+  int64_t m_lim = m;
+  if (m_dev != nullptr) {
+    const int64_t v = *m_dev;
+    if (v < m_lim) m_lim = v;
+  }
+  const int col = blockIdx.x * kThreads + threadIdx.x;
+  const int64_t m_beg = static_cast<int64_t>(blockIdx.y) * m_chunk;
+  int64_t m_end = m_beg + m_chunk;
+  if (m_end > m_lim) m_end = m_lim;
+  if (col >= n || m_beg >= m_end) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t r = m_beg;
+  for (; r + 3 < m_end; r += 4) {
+    s0 += dout[r * ld + col];
+    s1 += dout[(r + 1) * ld + col];
+    s2 += dout[(r + 2) * ld + col];
+    s3 += dout[(r + 3) * ld + col];
+  }
+  for (; r < m_end; ++r) s0 += dout[r * ld + col];
+  atomicAdd(dbias + col, (s0 + s1) + (s2 + s3));
+}
+
 }  // namespace
 }  // namespace sage
 
@@ -1419,11 +1472,20 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
     bool vec4 = true;
     for (int sgi = 0; sgi < g.nseg; ++sgi) vec4 = vec4 && g.seg[sgi].a.vec == 4 && g.seg[sgi].b.vec == 4;
     const int64_t steps = tiles * (cdiv(k1, BK) + cdiv(k2, BK));
-    if (x3_mode() && (epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && n > 64 && slots > 0 &&
-        vec4 && steps >= 6ll * slots) {
-      if (!accum) zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
-      SAGE_CHECK_LAUNCH("zero_rows_kernel");
-      gemm_x3_kernel<<<dim3(static_cast<unsigned>(slots / 2 * 3)), kThreads, 0, stream>>>(g);
+    const bool plain = (epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE;
+    const int64_t grid_x3 = slots / 2 * 3;      // three resident workgroups per CU
+    // many tiles per workgroup: whole tiles (plain stores, bias / relu epilogue, out += by
+    // load-add-store), the uneven last round costs little; few: stream-K pieces with atomics
+    const bool whole = tiles >= 8 * grid_x3 || (!plain && tiles >= 2 * grid_x3);
+    if (x3_mode() && (plain || whole) && n > 64 && slots > 0 && vec4 && steps >= 6ll * slots) {
+      if (whole) {
+        g.whole = 1;
+        g.rmw_out = accum ? 1 : 0;
+      } else if (!accum) {
+        zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
+        SAGE_CHECK_LAUNCH("zero_rows_kernel");
+      }
+      gemm_x3_kernel<<<dim3(static_cast<unsigned>(grid_x3)), kThreads, 0, stream>>>(g);
       SAGE_CHECK_LAUNCH("gemm_x3_kernel");
       return SAGE_OK;
     }
@@ -1446,7 +1508,7 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
     SAGE_CHECK_LAUNCH("gemm_kernel(fwd, stream-K)");
     return SAGE_OK;
   }
-  if (accum) g.atomic_out = 1;   // out += product
+  if (accum) g.rmw_out = 1;   // out += product: every element has one owner, plain load-add-store
   return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");
 }
 
@@ -1557,7 +1619,14 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   if (splits < 1) splits = 1;
   g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
   splits = cdiv(m, g.k_chunk);
-  if (x3_mode() && dbias == nullptr && k > 64 && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && m >= 64 * BK) {
+  if (x3_mode() && k > 64 && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && m >= 64 * BK) {
+    if (dbias != nullptr) {   // the bf16x3 kernel has no column-sum side output
+      const int m_chunk = 256;
+      const dim3 cgrid(static_cast<unsigned>(cdiv(n, kThreads)), static_cast<unsigned>(cdiv(m, m_chunk)));
+      colsum_kernel<<<cgrid, kThreads, 0, stream>>>(dout, ld_dout, m, m_dev, n, m_chunk, dbias);
+      SAGE_CHECK_LAUNCH("colsum_kernel");
+      g.colsum = nullptr;
+    }
     const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(cdiv(k, 128)),
                     static_cast<unsigned>(splits));
     gemm_x3_dw_kernel<<<grid, kThreads, 0, stream>>>(g);

@@ -17,7 +17,8 @@ namespace {
 
 constexpr int kBlock = 256;
 
-// slots[t, j] = row id of the j-th input of target t; nonempty[t] = segment has an edge.
+// slots[j, t] = row id of the j-th input of target t (slot-major: the n_in row maps of the gates
+// contraction's K-segments are contiguous vectors); nonempty[t] = segment has an edge.
 __global__ void segment_slots_kernel(const int64_t* __restrict__ seg_ptr,
                                      const int64_t* __restrict__ src,
                                      const int64_t* __restrict__ node_map, int64_t num_targets,
@@ -25,8 +26,8 @@ __global__ void segment_slots_kernel(const int64_t* __restrict__ seg_ptr,
                                      float* __restrict__ nonempty) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= num_targets * n_in) return;
-  const int64_t t = i / n_in;
-  const int j = static_cast<int>(i - t * n_in);
+  const int j = static_cast<int>(i / num_targets);
+  const int64_t t = i - j * num_targets;
   const int64_t s0 = seg_ptr[t];
   const int64_t len = seg_ptr[t + 1] - s0;
   int64_t id = 0;

@@ -14,37 +14,85 @@ reference graphsage/layers/sage.py:67-69) and the computation its aggregate() is
 broken (settings.py:48-50) — it keys its dict by SOURCE ids, indexes the per-edge tensor with
 node ids (:164) and returns rows in set-iteration order (:193) — so there is no reference output
 to match; tests compare against oracle/sage_ref.lstm_aggregate_ref, which restates the list
-above with torch.nn.functional on the CPU.
+above with torch.nn.functional on the CPU, and at the Reddit shape against torch.nn.LSTMCell.
 
-Kernels: slot indices (HIP) -> row gather (HIP) -> gates = x_flat @ W_ih^T + b_ih + b_hh on the
-fp32 MFMA GEMM -> zero-state cell non-linearity (HIP).  W_hh multiplies the zero hidden state
-and receives a zero gradient, exactly as in the reference's single-step use.
+Kernels: slot indices (HIP) -> gates = x_flat @ W_ih^T + b_ih + b_hh on the MFMA GEMM -> zero-state
+cell non-linearity (HIP).  x_flat [T, n_in*F] (0.8 GB at the Reddit shape) is never materialised:
+the contraction runs as n_in K-segments of width F, segment j reading the feature rows through
+its own row map slots[j] (two segments per launch, `out +=`).  The forget gate multiplies the
+zero initial cell state, so its quarter of W_ih is neither multiplied nor given a gradient
+(3/4 of the flops); W_hh multiplies the zero hidden state and receives a zero gradient, exactly
+as in the reference's single-step use.
 """
 import torch
 from torch.autograd import Function
 
-from .. import functional as SF
 from .. import ops
 
 
-class _GatherRowsFn(Function):
-    """x[idx] with a scatter-add backward (kernel: gather_reduce_bwd over unit segments)."""
+def _blocks(fdim):
+    """Row blocks of W_ih (torch order i, f, g, o) that reach the output from a zero state."""
+    return ((0, fdim), (2 * fdim, 4 * fdim))
+
+
+class _LstmGatesFn(Function):
+    """gates[t] = sum_j x[slots[j, t]] @ W_ih[:, jF:(j+1)F]^T + bias   (rows of the f gate: bias only)."""
 
     @staticmethod
-    def forward(ctx, x, idx):
-        ctx.save_for_backward(idx)
-        ctx.xshape = tuple(x.shape)
-        return ops.gather_rows(x if x.stride(-1) == 1 else x.contiguous(), idx, checked=True)
+    def forward(ctx, x, slots, w_ih, bias):
+        n_in, T = slots.shape
+        fdim = x.size(1)
+        x = ops.aligned_rows(x)
+        # W_ih [4F, n_in*F] re-laid as [4F, n_in, ld] with 64-byte aligned segments (F = 602: ld 608)
+        ld = (fdim + 15) // 16 * 16
+        w_pad = torch.zeros((4 * fdim, n_in, ld), dtype=torch.float32, device=x.device)
+        w_pad[:, :, :fdim].copy_(w_ih.view(4 * fdim, n_in, fdim))
+        gates = torch.empty((T, 4 * fdim), dtype=torch.float32, device=x.device)
+        gates.copy_(bias.unsqueeze(0).expand(T, 4 * fdim))
+        if T > 0:
+            for j in range(0, n_in, 2):
+                two = j + 1 < n_in
+                for r0, r1 in _blocks(fdim):
+                    ops.linear_concat_fwd(x, w_pad[r0:r1, j, :fdim], x if two else None,
+                                          w_pad[r0:r1, j + 1, :fdim] if two else None,
+                                          rows1=slots[j], rows2=slots[j + 1] if two else None, m=T,
+                                          out=gates[:, r0:r1], accumulate=True)
+        ctx.save_for_backward(x, slots, w_pad)
+        ctx.fdim = fdim
+        return gates
 
     @staticmethod
-    def backward(ctx, dout):
-        (idx,) = ctx.saved_tensors
-        if not ctx.needs_input_grad[0]:
-            return None, None
-        dx = torch.zeros(ctx.xshape, dtype=torch.float32, device=dout.device)
-        unit = torch.arange(idx.numel() + 1, dtype=torch.int64, device=dout.device)
-        ops.gather_reduce_bwd(dout.contiguous(), unit, idx, idx.numel(), "sum", dx)
-        return dx, None
+    def backward(ctx, dgates):
+        x, slots, w_pad = ctx.saved_tensors
+        n_in, T = slots.shape
+        fdim = ctx.fdim
+        dgates = dgates.contiguous()
+        dx = dw = dbias = None
+        if ctx.needs_input_grad[3]:
+            dbias = dgates.sum(0)
+        if ctx.needs_input_grad[2]:
+            dw_pad = torch.zeros_like(w_pad)
+            if T > 0:
+                for j in range(0, n_in, 2):
+                    for r0, r1 in _blocks(fdim):
+                        g = dgates[:, r0:r1]
+                        if j + 1 < n_in:
+                            ops.linear_dweight2(g, x, dw_pad[r0:r1, j, :fdim], x, dw_pad[r0:r1, j + 1, :fdim],
+                                                m=T, rows1=slots[j], rows2=slots[j + 1])
+                        else:
+                            ops.linear_dweight(g, x, m=T, rows=slots[j], dw=dw_pad[r0:r1, j, :fdim])
+            dw = dw_pad[:, :, :fdim].reshape(4 * fdim, n_in * fdim)
+        if ctx.needs_input_grad[0]:
+            dx = ops.empty_rows(x.size(0), fdim, x.device, zero=True)
+            if T > 0:
+                tmp = ops.empty_rows(T, fdim, x.device)
+                unit = torch.arange(T + 1, dtype=torch.int64, device=x.device)
+                for j in range(n_in):
+                    (a0, a1), (b0, b1) = _blocks(fdim)
+                    ops.linear_dinput(dgates[:, a0:a1], w_pad[a0:a1, j, :fdim], m=T, out=tmp)
+                    ops.linear_dinput(dgates[:, b0:b1], w_pad[b0:b1, j, :fdim], m=T, out=tmp, accumulate=True)
+                    ops.gather_reduce_bwd(tmp, unit, slots[j], T, "sum", dx)     # dx[slots[j, t]] += tmp[t]
+        return dx, None, dw, dbias
 
 
 class _LstmCell0Fn(Function):
@@ -64,9 +112,9 @@ class _LstmCell0Fn(Function):
 def lstm_aggregate(layer, x_src, plan, num_targets, node_map=None):
     n_in = layer.lstm_n_inputs
     fdim = x_src.size(1)
+    if node_map is not None and x_src.requires_grad:
+        raise RuntimeError("gradient w.r.t. a node_map'ed feature table is not supported")
     slots, nonempty = ops.segment_slots(plan.seg_ptr, plan.src, num_targets, n_in, node_map=node_map)
-    rows = _GatherRowsFn.apply(x_src, slots)                       # [T*n_in, F]
-    x_flat = rows.view(num_targets, n_in * fdim)
     bias = layer.lstm.bias_ih + layer.lstm.bias_hh
-    gates = SF.linear_concat(x_flat, layer.lstm.weight_ih, bias=bias)
+    gates = _LstmGatesFn.apply(x_src, slots, layer.lstm.weight_ih, bias)
     return _LstmCell0Fn.apply(gates, nonempty, fdim)

@@ -691,16 +691,17 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
 
 # ------------------------------------------------------------------------------- a-7
 def segment_slots(seg_ptr, src, num_targets, n_in, node_map=None):
-    """Per target, the row ids of its first n_in inputs (padded with the first) + nonempty mask."""
+    """Per target, the row ids of its first n_in inputs (padded with the first) + nonempty mask.
+    slots is [n_in, T] (slot-major): slots[j] is the row map of input j over all targets."""
     lib = _lib.load()
     T = int(num_targets)
     if seg_ptr.numel() < T + 1:
         raise RuntimeError("segment_slots: seg_ptr shorter than num_targets+1")
-    slots = torch.empty(T * n_in, dtype=torch.int64, device=seg_ptr.device)
+    slots = torch.empty((int(n_in), T), dtype=torch.int64, device=seg_ptr.device)
     nonempty = torch.empty(T, dtype=torch.float32, device=seg_ptr.device)
     rc = lib.sage_segment_slots(_vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"),
                                 _vec(node_map, torch.int64, "node_map", allow_none=True), T, int(n_in),
-                                _vec(slots, torch.int64, "slots"), _vec(nonempty, torch.float32, "nonempty"),
+                                _vec(slots.view(-1), torch.int64, "slots"), _vec(nonempty, torch.float32, "nonempty"),
                                 _stream())
     _lib.check(rc, "sage_segment_slots")
     return slots, nonempty

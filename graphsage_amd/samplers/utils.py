@@ -7,8 +7,6 @@ start nodes (utils.py:22) — an indexing quirk whose result depends on upstream
 cannot be reproduced without torch_cluster; parity for this function is therefore unpinned
 and the paper's intent is implemented.  Features are gathered on the device
 (the reference round-trips through the CPU, utils.py:27,32)."""
-import torch
-
 from .. import ops
 from ..data import Data
 from .uniform_loader import device_graph
@@ -16,15 +14,17 @@ from .uniform_loader import device_graph
 _counter = [0]
 
 
-def get_pos_neg_batches(batch, data, seed=0):
+def get_pos_neg_batches(batch, data, seed=0, counter=None):
+    """seed / counter: the Philox key and counter of both draws (counter=None: a module-level
+    count of calls).  With the batch's own sampler counter this is exactly what the static-shape
+    engine draws for that batch (engine.make_pos_neg), and what oracle/sampler.py restates."""
     graph = device_graph(data)
     n_id = batch.n_id.to(graph.device)
-    _counter[0] += 1
-    pos_n_id = ops.random_neighbor(graph.colptr, graph.row, n_id, seed, _counter[0])
-    gen = torch.Generator(device=graph.device)
-    gen.manual_seed(seed * 1000003 + _counter[0])
-    neg_n_id = torch.randint(0, data.num_nodes, (n_id.numel(),), dtype=torch.long,
-                             device=graph.device, generator=gen)
+    if counter is None:
+        _counter[0] += 1
+        counter = _counter[0]
+    pos_n_id = ops.random_neighbor(graph.colptr, graph.row, n_id, seed, counter)
+    neg_n_id = ops.random_nodes(data.num_nodes, n_id.numel(), seed, counter, device=graph.device)
     table = graph.features(data)
     ei = batch.edge_index
     pos_batch = Data(x=ops.gather_rows(table, pos_n_id, checked=True), n_id=pos_n_id, edge_index=ei)

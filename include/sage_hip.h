@@ -311,15 +311,17 @@ int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1, s
  * neighbours' rows (padded by repeating the first, :164) are flattened to one vector (:179)
  * and fed to ONE LSTMCell(n_in*F, F) step from a zero state (:187).  The contraction
  * x_flat @ W_ih^T + (b_ih + b_hh) is sage_linear_concat_fwd; these are the other pieces.
- *   sage_segment_slots: slots[t*n_in + j] = row id (through node_map if given) of input j of
- *     target t; nonempty[t] = 1.0 if the target has an in-edge else 0.0 (its output is 0,
- *     the F.pad of layers/sage.py:121-122).
+ *   sage_segment_slots: slots[j*T + t] = row id (through node_map if given) of input j of
+ *     target t — slot-major, so that slots + j*T is the row map of K-segment j of the gates
+ *     contraction (x_flat is never materialised: sage_linear_concat_fwd reads segment j through
+ *     it); nonempty[t] = 1.0 if the target has an in-edge else 0.0 (its output is 0, the F.pad of
+ *     layers/sage.py:121-122).
  *   sage_lstm_cell0_fwd: gates [m, 4F] in torch's (i,f,g,o) order ->
  *     h = sigmoid(o) * tanh(sigmoid(i) * tanh(g)), zeroed where nonempty == 0.
  *   sage_lstm_cell0_bwd: dgates from dh (the forget-gate gradient is 0: c0 = 0).
  * ---------------------------------------------------------------------------------- */
 int sage_segment_slots(const sage_i64* seg_ptr, const sage_i64* src, const sage_i64* node_map,
-                       sage_i64 num_targets, int n_in, sage_i64* slots /*[T*n_in]*/,
+                       sage_i64 num_targets, int n_in, sage_i64* slots /*[n_in*T]*/,
                        float* nonempty /*[T]*/, void* stream);
 int sage_lstm_cell0_fwd(const float* gates, sage_i64 ld_gates, const float* nonempty, sage_i64 m,
                         int num_features, float* h, sage_i64 ld_h, void* stream);

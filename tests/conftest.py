@@ -18,3 +18,20 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+REDDIT = dict(N=232965, E=114615892, FEAT=602, C=41)
+
+
+@pytest.fixture(scope="session")
+def reddit(dev):
+    """The Reddit-SHAPED synthetic graph of bench.py (BASELINE.json configs[2]/[3]) with its CSC
+    and padded feature table resident on the device; built once per test session (~6 GB)."""
+    import torch
+    from graphsage_amd.datasets import reddit_like_device
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = reddit_like_device(REDDIT["N"], REDDIT["E"], REDDIT["FEAT"], REDDIT["C"], seed=0, device=dev)
+    graph = device_graph(data)
+    yield data, graph
+    del data, graph
+    torch.cuda.empty_cache()

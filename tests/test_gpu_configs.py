@@ -1,0 +1,349 @@
+"""BASELINE.json's configurations at THEIR OWN shapes (the small-shape oracle tests live in
+test_gpu_model.py / test_gpu_trainers.py):
+
+  configs[0]  Cora supervised GraphSAGE-mean, 2,708 nodes / 10,556 edges / F = 1,433 -> 256 -> 7,
+              140 train seeds, fan-out 25/10 (reference examples/citation_graphsage_supervised.py:19-36)
+              — end to end against the CPU oracle (it finishes in seconds at this size);
+  configs[3]  Reddit-shape max_pool / mean_pool step and the lstm layer (reference
+              layers/sage.py:75-76, :201-207; :67-69, :147-193) — against plain torch ops on the
+              device (index_select, scatter_reduce, F.linear, nn.LSTMCell; none of the library's
+              kernels), because the CPU oracle would take minutes there;
+  configs[4]  products-scale graph (N = 2.4 M, E = 62 M, F = 100), unsupervised random-walk loss:
+              sampler invariants, positive / negative ids, and one engine step (unsup='only')
+              against the module path and plain torch ops.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import csc, sage_ref, sampler
+from tests.helpers import load_layers, make_layers
+
+pytestmark = pytest.mark.gpu
+B, FAN = 512, [25, 10]
+
+
+# ------------------------------------------------------------------------------------ configs[0]
+def test_cora_true_shape_training_matches_oracle(dev):
+    """Three epochs of the one-batch Cora epoch (140 seeds < 512 = one batch per epoch, as in the
+    reference) on the module path AND the static-shape engine against the oracle: sampled ids
+    bit-exact, logits, loss, gradients, parameters after each Adam step (lr 0.01,
+    examples/citation_graphsage_supervised.py:31)."""
+    from graphsage_amd.datasets import Planetoid
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler, UniformLoader
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    ds = Planetoid(name='Cora')
+    data = ds[0]
+    assert (data.num_nodes, data.edge_index.size(1), ds.num_features, ds.num_classes) == (2708, 10556, 1433, 7)
+    train = data.train_mask.nonzero().view(-1)
+    nb = int(train.numel())
+    assert nb == 140
+    lr, rng_seed = 0.01, 21
+    layers = make_layers([1433, 256, 7], "mean", 3)
+    model = GraphSAGE(1433, 256, "mean", 2, 7).to(dev)
+    load_layers(model, layers)
+    emodel = copy.deepcopy(model)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    loader = UniformLoader(data, num_neighbors=FAN, input_nodes=data.train_mask, batch_size=512, shuffle=False,
+                           seed=rng_seed)
+    assert len(loader) == 1
+    graph = device_graph(data)
+    engine = SageTrainEngine(emodel, NeighborSampler(data, FAN, seed=rng_seed), graph.features(data),
+                             graph.labels(data), nb, lr=lr, keep_grads=True)
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), data.num_nodes)
+    params = [{k: v.clone() for k, v in p.items()} for p in layers]
+    state = [{k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()} for p in params]
+    # Adam divides by |g| + 1e-8: where a gradient element is itself ~1e-8 its update is decided
+    # by rounding noise, so two trajectories cannot be compared element by element.  Instead: the
+    # gradients are compared with the oracle's every step, the device Adam step is checked as a
+    # FUNCTION (adam_ref applied to the engine's own gradients must reproduce the engine's new
+    # parameters), and the trajectories must stay together in norm and in loss.
+    estate = [{k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()} for p in params]
+    for epoch in range(3):
+        (batch,) = list(loader)                  # Philox counter = epoch (one batch per epoch)
+        node, src, dst, eid, _, _ = sampler.neighbor_sample(c0, r0, train.numpy(), FAN, rng_seed, epoch)
+        assert batch.n_id.cpu().numpy().tolist() == node.tolist()
+        assert batch.edge_index.cpu().numpy().tolist() == [src.tolist(), dst.tolist()]
+        leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+        want_loss, want_logits = sage_ref.train_step_loss(data.x, data.y, torch.from_numpy(node),
+                                                          torch.from_numpy(src), torch.from_numpy(dst), nb, leaf)
+        want_loss.backward()
+        # module path (what the reference's script drives)
+        opt.zero_grad()
+        y_hat = model(batch.x, batch.edge_index)[:batch.batch_size]
+        loss = F.cross_entropy(y_hat, batch.y[:batch.batch_size])
+        loss.backward()
+        torch.testing.assert_close(y_hat.detach().cpu(), want_logits.detach(), rtol=1e-4, atol=2e-5)
+        torch.testing.assert_close(loss.detach().cpu(), want_loss.detach(), rtol=1e-5, atol=1e-6)
+        # engine on the same seeds and counter
+        eprev = [{k: getattr(em, k).weight.detach().cpu().clone() for k in p} for em, p in zip(emodel.layers, params)]
+        eloss = engine.step(train.to(dev), counter=epoch)
+        torch.testing.assert_close(eloss.cpu().view(()), want_loss.detach(), rtol=1e-5, atol=1e-6)
+        for m, em, lf in zip(model.layers, emodel.layers, leaf):
+            for k in ("lin_l", "lin_r"):
+                torch.testing.assert_close(getattr(m, k).weight.grad.cpu(), lf[k].grad, rtol=1e-3, atol=1e-6)
+                torch.testing.assert_close(engine.gviews[getattr(em, k).weight].cpu(), lf[k].grad, rtol=1e-3, atol=1e-6)
+        opt.step()
+        for p, lf, st in zip(params, leaf, state):
+            for k in p:
+                p[k], m1, v1 = sage_ref.adam_ref(p[k], lf[k].grad, st[k][0], st[k][1], epoch + 1, lr)
+                st[k] = (m1, v1)
+        for m, em, p, prev, est in zip(model.layers, emodel.layers, params, eprev, estate):
+            for k in p:
+                g_dev = engine.gviews[getattr(em, k).weight].cpu()
+                want_p, m1, v1 = sage_ref.adam_ref(prev[k], g_dev, est[k][0], est[k][1], epoch + 1, lr)
+                est[k] = (m1, v1)
+                torch.testing.assert_close(getattr(em, k).weight.detach().cpu(), want_p, rtol=1e-5, atol=1e-7)
+                for got in (getattr(m, k).weight.detach().cpu(), getattr(em, k).weight.detach().cpu()):
+                    assert float((got - p[k]).norm() / p[k].norm()) < 1e-3
+                    assert float((got - p[k]).abs().max()) <= 2.0 * lr * (epoch + 1)
+    # evaluation of the reference's test(): sampled 25/10 neighbourhoods of the 1,000 test nodes
+    test_ids = data.test_mask.nonzero().view(-1)
+    correct, count = engine.evaluate(test_ids.to(dev), counter0=500)
+    hit = 0
+    for b in range(0, 1000, nb):
+        chunk = test_ids[b:b + nb]
+        pad = torch.cat([chunk, chunk[:1].expand(nb - chunk.numel())]) if chunk.numel() < nb else chunk
+        node, src, dst, _, _, _ = sampler.neighbor_sample(c0, r0, pad.numpy(), FAN, rng_seed, 500 + b // nb)
+        out = sage_ref.graphsage_forward(data.x[node], torch.from_numpy(np.stack([src, dst])), params)
+        hit += int((out[:chunk.numel()].argmax(-1) == data.y[chunk]).sum())
+    assert int(count) == 1000 and abs(int(correct) - hit) <= 5      # within 0.5 pt micro-F1
+
+
+# ------------------------------------------------------------------------------------ configs[3]
+def _reddit_batch(graph, dev, counter=5):
+    from graphsage_amd import ops
+    N = graph.num_nodes
+    seeds = torch.randperm(N, generator=torch.Generator().manual_seed(7))[:B].to(dev)
+    buf = ops.SampleBuffers(N, B * (1 + 25 + 250), B * (25 + 250), dev)
+    table = ops.new_relabel_table(N, dev)
+    ops.sample_fanout(graph.colptr, graph.row, seeds, FAN, 0, counter, table, 1, buf)
+    st = buf.state.tolist()
+    assert st[ops.ST_ERROR] == 0
+    return seeds, buf, st
+
+
+def _plain_pool_layer(h, ei, n, pw, pb, wl, wr, reduce):
+    """layers/sage.py:201-210 as written: the pool Linear + ReLU on PER-EDGE rows, then scatter."""
+    x_j = F.relu(F.linear(h[ei[0]], pw, pb))
+    fdim = x_j.size(1)
+    if reduce == "max":
+        agg = torch.zeros(n, fdim, device=h.device).scatter_reduce(
+            0, ei[1].unsqueeze(1).expand(-1, fdim), x_j, "amax", include_self=False)
+    else:
+        agg = torch.zeros(n, fdim, device=h.device).index_add_(0, ei[1], x_j)
+        agg = agg / torch.bincount(ei[1], minlength=n).clamp(min=1).unsqueeze(1)
+    return F.normalize(F.linear(agg, wl) + F.linear(h, wr), p=2.0, dim=-1)
+
+
+@pytest.mark.parametrize("aggregator", ["max_pool", "mean_pool"])
+def test_reddit_shape_pool_step_matches_plain_torch(reddit, dev, aggregator):
+    """One fig2a step with a pooling aggregator at the Reddit shape (602 -> 256 -> 41, B = 512,
+    25/10): logits, loss and every gradient (pool weight / bias included) against the layer written
+    out in plain torch ops with the pool Linear applied per EDGE as in the reference (the
+    library applies it once per source node).  Max ties only occur at the ReLU's zeros, where both
+    routings give a zero gradient."""
+    from graphsage_amd.models import GraphSAGE
+    data, graph = reddit
+    seeds, buf, st = _reddit_batch(graph, dev)
+    nn_, ne, t1, e1 = st[0], st[1], st[9], st[25]
+    node = buf.node[:nn_]
+    torch.manual_seed(1)
+    model = GraphSAGE(602, 256, aggregator, 2, 41).to(dev)
+    ref = [{k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()} for m in model.layers]
+    # module path on the sampled batch (tensor form: x = batch.x, edge_index with the loader's plan)
+    from graphsage_amd import functional as SF
+    ei = torch.stack([buf.src[:ne], buf.dst[:ne]])
+    ei._sage_plan = SF.EdgePlan(buf.seg_ptr[:nn_ + 1].clone(), buf.src[:ne], nn_, nn_,
+                                hop_nodes=[st[8], st[9], st[10]], hop_edges=[st[24], st[25], st[26]])
+    x = data.x[node]
+    y_hat = model(x, ei)[:B]
+    loss = F.cross_entropy(y_hat, data.y[seeds])
+    loss.backward()
+    # plain torch, pruned to the rows that reach the seeds (layer 0: targets [0, t1) over all
+    # edges; layer 1: the seeds over the e1 edges into them) — identical on [:B]
+    red = "max" if aggregator == "max_pool" else "mean"
+    p0, p1 = ref
+    h0 = _plain_pool_layer(x, ei, nn_, p0["pool.weight"], p0["pool.bias"], p0["lin_l.weight"],
+                           p0["lin_r.weight"], red)[:t1].relu()
+    ei1 = ei[:, :e1]
+    want = _plain_pool_layer(h0, ei1, t1, p1["pool.weight"], p1["pool.bias"], p1["lin_l.weight"],
+                             p1["lin_r.weight"], red)[:B]
+    want_loss = F.cross_entropy(want, data.y[seeds])
+    want_loss.backward()
+    torch.testing.assert_close(y_hat.detach(), want.detach(), rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(loss.detach(), want_loss.detach(), rtol=1e-5, atol=1e-6)
+    for m, p in zip(model.layers, ref):
+        for name, q in m.named_parameters():
+            got, w = q.grad, p[name].grad
+            err = float((got - w).norm() / w.norm().clamp(min=1e-30))
+            # max: a (target, feature) whose two best candidates agree to rounding noise may pick
+            # different edges in the two paths (different GEMM summation orders in the pool
+            # Linear), which moves that element's gradient to another source row
+            assert err < (1e-2 if aggregator == "max_pool" else 2e-3), (name, err)
+            # elementwise on all but the few units that sit on a ReLU kink in one path only
+            off = (got - w).abs() > 1e-7 + 2e-3 * w.abs()
+            assert int(off.sum()) <= 0.01 * off.numel(), (name, int(off.sum()))
+
+
+@pytest.mark.parametrize("n_in", [25, 5])
+def test_reddit_shape_lstm_layer_matches_torch_lstmcell(reddit, dev, n_in):
+    """The lstm aggregator's layer at the Reddit shape (T = seeds + hop-1 nodes ~ 12.4 k targets,
+    F = 602, gates contraction [T, n_in*602] x [n_in*602, 2408]) against torch.nn.LSTMCell on the
+    device fed with rows gathered by index arithmetic: forward, and the gradients w.r.t. W_ih, the
+    biases, lin_l / lin_r.  Parity with the reference is unpinned by construction (its lstm code
+    is disabled upstream as broken, settings.py:48-50); this is layers/lstm.py's reading."""
+    from graphsage_amd.layers import SAGE
+    from graphsage_amd import functional as SF
+    data, graph = reddit
+    seeds, buf, st = _reddit_batch(graph, dev, counter=6)
+    nn_, ne, t1 = st[0], st[1], st[9]
+    node = buf.node[:nn_]
+    torch.manual_seed(2)
+    layer = SAGE(602, 256, 'lstm')
+    layer.lstm_n_inputs = n_in
+    layer.lstm = torch.nn.LSTMCell(n_in * 602, 602)
+    layer = layer.to(dev)
+    plan = SF.EdgePlan(buf.seg_ptr[:nn_ + 1].clone(), buf.src[:ne], nn_, nn_)
+    feats = graph.features(data)
+    out = layer.apply_plan(feats, feats, plan, t1, relu=True, node_map=node)
+    g = torch.randn(t1, 256, generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+    out.backward(g)
+    got = {k: v.grad.clone() for k, v in layer.named_parameters() if v.grad is not None}
+    # plain torch: slot j of target t = its j-th in-neighbour, or its first one when it has fewer
+    seg = buf.seg_ptr[:t1 + 1]
+    cnt = seg[1:] - seg[:-1]
+    j = torch.arange(n_in, device=dev).unsqueeze(0)
+    pos = seg[:-1].unsqueeze(1) + torch.where(j < cnt.unsqueeze(1), j, torch.zeros_like(j))
+    pos = pos.clamp(max=max(ne - 1, 0))
+    rows = node[buf.src[:ne][pos]]                                   # [T, n_in] global ids
+    x_flat = data.x[rows.view(-1)].view(t1, n_in * 602)
+    cell = copy.deepcopy(layer.lstm)
+    cell.zero_grad()
+    wl = layer.lin_l.weight.detach().clone().requires_grad_(True)
+    wr = layer.lin_r.weight.detach().clone().requires_grad_(True)
+    h, _ = cell(x_flat)
+    h = h * (cnt > 0).unsqueeze(1)
+    want = F.normalize(F.linear(h, wl) + F.linear(data.x[node[:t1]], wr), p=2.0, dim=-1).relu()
+    want.backward(g)
+    torch.testing.assert_close(out.detach(), want.detach(), rtol=1e-4, atol=3e-5)
+    pairs = [("lstm.weight_ih", cell.weight_ih.grad), ("lstm.bias_ih", cell.bias_ih.grad),
+             ("lstm.bias_hh", cell.bias_hh.grad), ("lin_l.weight", wl.grad), ("lin_r.weight", wr.grad)]
+    for name, w in pairs:
+        err = float((got[name] - w).norm() / w.norm())
+        assert err < 2e-3, (name, err)
+    # W_hh multiplies the zero initial state: zero gradient (or none) on both sides
+    assert "lstm.weight_hh" not in got or float(got["lstm.weight_hh"].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------ configs[4]
+PN, PE, PF = 2_400_000, 62_000_000, 100
+
+
+@pytest.fixture(scope="module")
+def products(dev):
+    from graphsage_amd.datasets import reddit_like_device
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = reddit_like_device(PN, PE, PF, 47, seed=0, device=dev)
+    graph = device_graph(data)
+    yield data, graph
+    del data, graph
+    torch.cuda.empty_cache()
+
+
+def test_products_scale_sampler_invariants(products, dev):
+    from graphsage_amd import ops
+    data, graph = products
+    colptr, row = graph.colptr, graph.row
+    assert int(colptr[-1]) == PE and colptr.numel() == PN + 1
+    assert torch.equal(colptr[1:] - colptr[:-1], torch.bincount(data.edge_index[1], minlength=PN))
+    seeds = torch.randperm(PN, generator=torch.Generator().manual_seed(1))[:B].to(dev)
+    buf = ops.SampleBuffers(PN, B * (1 + 25 + 250), B * (25 + 250), dev)
+    table = ops.new_relabel_table(PN, dev)
+    ops.sample_fanout(colptr, row, seeds, FAN, 0, 9, table, 1, buf)
+    st = buf.state.tolist()
+    nn_, ne = st[0], st[1]
+    assert st[4] == 0 and ne > 20000
+    node, src, dst, eid = buf.node[:nn_], buf.src[:ne], buf.dst[:ne], buf.eid[:ne]
+    seg = buf.seg_ptr[:nn_ + 1]
+    assert torch.equal(node[:B], seeds) and node.unique().numel() == nn_
+    assert torch.equal(row[eid], node[src])
+    assert torch.equal(torch.searchsorted(colptr, eid, right=True) - 1, node[dst])
+    deg = (colptr[1:] - colptr[:-1])[node]
+    k = torch.where(torch.arange(nn_, device=dev) < B, 25, 10)
+    want = torch.minimum(deg, k)
+    want[st[9]:] = 0
+    assert torch.equal(seg[1:] - seg[:-1], want)
+    assert (dst * (PE + 1) + eid).unique().numel() == ne               # without replacement
+    # mean degree 26: both branches of the sampler (take-all and Floyd) are exercised
+    assert int((deg[:st[9]] <= k[:st[9]]).sum()) > 0 and int((deg[:st[9]] > k[:st[9]]).sum()) > 0
+    # positives are in-neighbours (or the node itself when it has none), negatives are in range
+    pos = ops.random_neighbor(colptr, row, node, 0, 9)
+    neg = ops.random_nodes(PN, nn_, 0, 9, device=dev)
+    lo, hi = colptr[node], colptr[node + 1]
+    for i in torch.randint(0, nn_, (64,), generator=torch.Generator().manual_seed(0)).tolist():
+        nbrs = row[int(lo[i]):int(hi[i])]
+        assert (int(pos[i]) == int(node[i])) if nbrs.numel() == 0 else bool((nbrs == pos[i]).any())
+    assert int(neg.min()) >= 0 and int(neg.max()) < PN and neg.unique().numel() > 0.9 * nn_
+
+
+def test_products_scale_unsup_engine_step_matches_module_path(products, dev):
+    """BASELINE.json configs[4]: one step of the unsupervised trainer
+    (trainers/node_level_graphsage_trainers.py:104-117, base_trainers.py:170-181) on the
+    static-shape engine (unsup='only', 100 -> 256 -> 256) against the module path
+    (get_pos_neg_batches + three model forwards + autograd) and against plain torch ops."""
+    from graphsage_amd.data import Data
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler, get_pos_neg_batches
+    from graphsage_amd import functional as SF
+    data, graph = products
+    torch.manual_seed(0)
+    model = GraphSAGE(PF, 256, "mean", 2, 256).to(dev)
+    ref_model = copy.deepcopy(model)
+    before = [p.detach().clone() for p in model.parameters()]
+    engine = SageTrainEngine(model, NeighborSampler.from_graph(graph, FAN, seed=4), graph.features(data),
+                             graph.labels(data), B, lr=1e-3, unsup='only', keep_grads=True)
+    seeds = torch.randperm(PN, generator=torch.Generator().manual_seed(3))[:B].to(dev)
+    loss = engine.step(seeds, counter=31)
+    buf = engine.buf
+    st = buf.state.tolist()
+    nn_, ne = st[0], st[1]
+    node = buf.node[:nn_].clone()
+    ei = torch.stack([buf.src[:ne], buf.dst[:ne]])
+    ei._sage_plan = SF.EdgePlan(buf.seg_ptr[:nn_ + 1].clone(), buf.src[:ne].clone(), nn_, nn_,
+                                hop_nodes=[st[8], st[9], st[10]], hop_edges=[st[24], st[25], st[26]])
+    batch = Data(x=data.x[node], n_id=node, edge_index=ei)
+    batch.batch_size = B
+    pos_b, neg_b = get_pos_neg_batches(batch, data, seed=4, counter=31)
+    assert torch.equal(pos_b.n_id, engine.pos_id[:nn_]) and torch.equal(neg_b.n_id, engine.neg_id[:nn_])
+    out = ref_model(batch.x, ei)[:B]
+    pos_out = ref_model(pos_b.x, ei)[:B]
+    neg_out = ref_model(neg_b.x, ei)[:B]
+    ref_loss = -F.logsigmoid((out * pos_out).sum(-1)).mean() - F.logsigmoid(-(out * neg_out).sum(-1)).mean()
+    ref_loss.backward()
+    torch.testing.assert_close(loss.view(()), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+    for p, q in zip(model.parameters(), ref_model.parameters()):
+        got, want = engine.gviews[p], q.grad
+        err = float((got - want).norm() / want.norm())
+        assert err < 1e-3, err
+        off = (got - want).abs() > 1e-7 + 1e-3 * want.abs()
+        assert int(off.sum()) <= 0.01 * off.numel(), int(off.sum())
+    # plain torch ops on the three feature sets
+    def plain(ids):
+        h = data.x[ids]
+        for i, (wl, wr) in enumerate(zip(before[0::2], before[1::2])):
+            agg = torch.zeros_like(h).index_add_(0, ei[1], h[ei[0]])
+            deg = torch.bincount(ei[1], minlength=nn_).clamp(min=1).unsqueeze(1)
+            h = F.normalize(F.linear(agg / deg, wl) + F.linear(h, wr), p=2.0, dim=-1)
+            if i == 0:
+                h = h.relu()
+        return h[:B]
+    o, p_, n_ = plain(node), plain(pos_b.n_id), plain(neg_b.n_id)
+    want = -F.logsigmoid((o * p_).sum(-1)).mean() - F.logsigmoid(-(o * n_).sum(-1)).mean()
+    torch.testing.assert_close(loss.view(()), want, rtol=1e-4, atol=1e-5)

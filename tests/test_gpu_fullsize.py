@@ -11,17 +11,6 @@ pytestmark = pytest.mark.gpu
 N, E, FEAT, C, B, FAN = 232965, 114615892, 602, 41, 512, [25, 10]
 
 
-@pytest.fixture(scope="module")
-def reddit(dev):
-    from graphsage_amd.datasets import reddit_like_device
-    from graphsage_amd.samplers.uniform_loader import device_graph
-    data = reddit_like_device(N, E, FEAT, C, seed=0, device=dev)
-    graph = device_graph(data)
-    yield data, graph
-    del data, graph
-    torch.cuda.empty_cache()
-
-
 def test_csc_build_full_size(reddit, dev):
     """to_csc (samplers/uniform_loader.py:32) on 114.6 M edges: colptr is the histogram's scan,
     perm is a permutation that sorts the edges by (col, row), row = edge_index[0][perm]."""

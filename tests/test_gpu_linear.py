@@ -73,7 +73,7 @@ def _pad16(x, dev):
 @pytest.mark.parametrize("m,n,k1,k2,m_frac", [(13100, 256, 602, 602, 1.0), (26000, 200, 130, 70, 0.6),
                                               (9000, 256, 512, 0, 1.0)])
 def test_linear_concat_fwd_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
-    """SAGE_GEMM_X3=1 (opt-in): the forward contraction on the bf16 MFMA with every fp32 operand
+    """bf16x3 mode (the default; SAGE_GEMM_X3=0 = exact-fp32 MFMA): the forward contraction on the bf16 MFMA with every fp32 operand
     split into three bf16 terms.  Against a float64 reference it must be as accurate as the
     exact-fp32 MFMA path on the same inputs (K / N tails, row map, device-side row count,
     accumulate), and it must actually have run (its bits differ from the fp32 path's; the shapes
@@ -98,11 +98,10 @@ def test_linear_concat_fwd_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
         out = torch.zeros((m, n), device=dev) if accumulate else torch.full((m, n), 7.0, device=dev)
         ops.linear_concat_fwd(*args, out=out, accumulate=accumulate, **kw)
         return out
-    monkeypatch.delenv("SAGE_GEMM_X3", raising=False)
+    monkeypatch.setenv("SAGE_GEMM_X3", "0")
     f32 = run(False)
-    monkeypatch.setenv("SAGE_GEMM_X3", "1")
+    monkeypatch.delenv("SAGE_GEMM_X3")            # bf16x3 is the default
     x3, x3_acc = run(False), run(True)
-    monkeypatch.delenv("SAGE_GEMM_X3")
     err_f32 = (f32[:m_live].double().cpu() - want[:m_live]).abs().max()
     for out in (x3, x3_acc):
         err = (out[:m_live].double().cpu() - want[:m_live]).abs().max()
@@ -114,7 +113,7 @@ def test_linear_concat_fwd_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
 @pytest.mark.parametrize("m,n,k1,k2,m_frac", [(13100, 256, 602, 602, 0.95), (9000, 128, 300, 0, 1.0),
                                               (4100, 200, 130, 258, 1.0)])
 def test_linear_dweight_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
-    """SAGE_GEMM_X3=1: the weight-gradient contractions (single and the layer's pair, row map,
+    """bf16x3 mode (the default): the weight-gradient contractions (single and the layer's pair, row map,
     device-side contraction length, column tails) on the bf16 MFMA through transposing LDS
     reads: as accurate against float64 as the exact-fp32 path, and really taken."""
     from graphsage_amd import ops
@@ -139,11 +138,10 @@ def test_linear_dweight_bf16x3_mode(dev, monkeypatch, m, n, k1, k2, m_frac):
         dw2 = torch.zeros((n, k2), device=dev)
         ops.linear_dweight2(dout_d, a1_d, dw1, table_d, dw2, m=m, m_dev=mdev, rows2=rows_d)
         return dw1, dw2
-    monkeypatch.delenv("SAGE_GEMM_X3", raising=False)
+    monkeypatch.setenv("SAGE_GEMM_X3", "0")
     f1, f2 = run()
-    monkeypatch.setenv("SAGE_GEMM_X3", "1")
+    monkeypatch.delenv("SAGE_GEMM_X3")            # bf16x3 is the default
     x1, x2 = run()
-    monkeypatch.delenv("SAGE_GEMM_X3")
     for got, ref, want in ((x1, f1, want1),) + (((x2, f2, want2),) if k2 else ()):
         err = (got.double().cpu() - want).abs().max()
         err_f32 = (ref.double().cpu() - want).abs().max()
