@@ -54,12 +54,16 @@ def parse():
     ap.add_argument("--group", type=int, default=4,
                     help="batches per cross-stream synchronisation of the eager pipeline (engine `group`)")
     ap.add_argument("--no-variant", action="store_true",
-                    help="skip the extra (untimed for `value`) measurement of the overlap_gather schedule")
+                    help="skip the informational extra measurement (exact-fp32 MFMA mode of the GEMMs)")
     ap.add_argument("--no-probe", action="store_true", help="do not time the gather kernel with events")
     ap.add_argument("--bracket-probe", action="store_true",
                     help="record the probe's events around the gather launch instead of attaching them to it")
-    ap.add_argument("--overlap-gather", action="store_true",
-                    help="run the layer-0 gather of batch s+1 on the side stream during batch s")
+    ap.add_argument("--serial", action="store_true",
+                    help="headline from the serial schedule (every kernel of a step on one stream) instead of "
+                         "the overlapped one (layer-0 gather of batch s+1 on the side stream beside batch s)")
+    ap.add_argument("--probe-steps", type=int, default=300,
+                    help="timed steps of the serial roofline probe run (gather kernel alone on its stream)")
+    ap.add_argument("--lstm-num-inputs", type=int, default=25, help="--aggregator lstm: LSTM_NUM_INPUTS")
     ap.add_argument("--variant", default="fig2a", choices=["fig2a", "trainer", "trainer-module", "unsup"],
                     help="fig2a: the benchmarked step (supervised term only). trainer: the reference "
                          "trainers' step (node_level_graphsage_trainers.py:34-46: + unsupervised term = two "
@@ -156,6 +160,92 @@ def trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, worl
         "roofline": None, "cpu_baseline": None, "final_loss": round(float(loss.detach()), 5), "variant": "trainer-module"}), flush=True)
 
 
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense peaks
+
+
+def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_mode):
+    """Aggregators the static-shape engine does not run (lstm; the pooling ones with
+    --module-path): fig2a's step through the module path (autograd Functions over the same
+    kernels).  `roofline` is for the dominant kernels here, the large MFMA contractions: every
+    sage_linear_concat_fwd / sage_linear_dweight(2) call above 1 GFLOP is bracketed by a HIP
+    event pair on its stream; achieved = sum of their flops / sum of their event times."""
+    import torch.nn.functional as F
+
+    from graphsage_amd import ops
+    from graphsage_amd.samplers import UniformLoader
+    gen = torch.Generator().manual_seed(0)
+    train = torch.randperm(N, generator=gen)[:n_train]
+    loader = UniformLoader(data, num_neighbors=K, input_nodes=train, batch_size=B, shuffle=False, seed=0)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    rec = {"on": False, "flops": 0.0, "pairs": []}
+
+    def bracket(name, flops_of):
+        inner = getattr(ops, name)
+
+        def wrapped(*a, **kw):
+            fl = flops_of(*a, **kw)
+            if not rec["on"] or fl < 1e9:
+                return inner(*a, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = inner(*a, **kw)
+            e1.record()
+            rec["flops"] += fl
+            rec["pairs"].append((e0, e1))
+            return out
+        setattr(ops, name, wrapped)
+
+    def fwd_flops(a1, w1, a2=None, w2=None, m=None, rows1=None, **kw):
+        mm = m if m is not None else (rows1.numel() if rows1 is not None else a1.size(0))
+        return 2.0 * mm * w1.size(0) * (w1.size(1) + (w2.size(1) if w2 is not None else 0))
+    bracket("linear_concat_fwd", fwd_flops)
+    bracket("linear_dweight", lambda dout, a, m=None, **kw: 2.0 * (m if m is not None else dout.size(0)) * dout.size(1) * a.size(1))
+    bracket("linear_dweight2", lambda dout, a1, dw1, a2, dw2, m=None, **kw:
+            2.0 * (m if m is not None else dout.size(0)) * dout.size(1) * (a1.size(1) + a2.size(1)))
+    bracket("linear_dinput", lambda dout, w, m=None, **kw: 2.0 * (m if m is not None else dout.size(0)) * w.size(0) * w.size(1))
+
+    def step(batch):
+        opt.zero_grad()
+        y_hat = model.forward_batch(batch)
+        loss = F.cross_entropy(y_hat, batch.y[:batch.batch_size])
+        loss.backward()
+        opt.step()
+        return loss
+
+    it = iter(loader)
+    for _ in range(args.warmup):
+        step(next(it))
+    torch.cuda.synchronize()
+    rec["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(next(it))
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gemm_ms = sum(a.elapsed_time(b) for a, b in rec["pairs"])
+    tf = rec["flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    # bf16x3: six bf16 MFMA products per fp32 product, so the fp32-equivalent peak is bf16 / 6
+    peak = MFMA_PEAK_TFLOPS["bf16"] / 6.0 if gemm_mode == "bf16x3" else MFMA_PEAK_TFLOPS["f32"]
+    extra = f", LSTM_NUM_INPUTS {args.lstm_num_inputs}" if args.aggregator == "lstm" else ""
+    print(json.dumps({
+        "metric": "Reddit GraphSAGE-mean 25/10 fwd+bwd seed nodes/s; gather GB/s vs HBM peak",
+        "value": round(B * args.steps / elapsed, 1), "unit": "seed nodes/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}-shaped synthetic: N={N} E={E} F={Fdim} C={C}, B={B}/GPU, fan-out {K}, "
+                               f"hidden {args.hidden}, aggregator {args.aggregator}{extra}, Adam lr {args.lr}, fig2a step "
+                               "(supervised term only), module path",
+                   "parallelism": "dp1", "global_batch": B},
+        "roofline": {"bound": "mfma", "kernel": "MFMA contractions above 1 GFLOP (gemm_x3_kernel / gemm_x3_dw_kernel / gemm_kernel)",
+                     "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                     "traffic": None, "flops_per_step": rec["flops"] / args.steps,
+                     "gemm_ms_per_step": round(gemm_ms / args.steps, 4), "launches_per_step": len(rec["pairs"]) / args.steps,
+                     "timing": "HIP events recorded around each call on its stream (fp32-equivalent flops; "
+                               "peak = bf16 dense peak / 6 products in bf16x3 mode)"},
+        "cpu_baseline": None, "gemm_mode": gemm_mode, "final_loss": round(float(loss.detach()), 5),
+        "variant": "module-path"}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,12 +257,19 @@ def main():
         # debugging aid: dump every thread's Python stack and exit if the run takes this long
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SAGE_BENCH_WATCHDOG"]), exit=True)
+    if world != args.gpus:
+        # n_gpus in the result is the number of ranks that really ran: refuse a launch whose
+        # world size is not what --gpus says (e.g. `python bench.py --gpus 8` without torchrun)
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch it with "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     # Rehearsal of the N > 1 path on a ONE-GPU box (never what the driver runs): with
     # SAGE_BENCH_BACKEND=gloo every rank uses cuda:0 and the gradient all-reduce goes over gloo
     # (RCCL refuses two ranks on one device).  The number it prints is not a scaling result.
     backend = os.environ.get("SAGE_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit(f"{world} ranks on a node with {torch.cuda.device_count()} visible GPUs: RCCL needs one GPU per rank")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -181,12 +278,12 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
             torch.distributed.init_process_group(backend)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        if torch.distributed.get_world_size() != world:
+            raise SystemExit("process group came up with fewer ranks than WORLD_SIZE")
 
-    from graphsage_amd import ops
+    from graphsage_amd import ops, settings
     from graphsage_amd.datasets import reddit_like_device
-    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.engine import _REDUCE, SageTrainEngine
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import NeighborSampler
     from graphsage_amd.samplers.uniform_loader import device_graph
@@ -194,25 +291,29 @@ def main():
     N, E, Fdim, C, n_train = SHAPES[args.workload]
     B, K = args.batch_size, list(args.fanout)
     t_setup = time.perf_counter()
-    gemm_mode = "bf16x3" if os.environ.get("SAGE_GEMM_X3", "")[:1] == "1" else "f32"
+    gemm_mode = "f32" if os.environ.get("SAGE_GEMM_X3", "")[:1] == "0" else "bf16x3"
     data = reddit_like_device(N, E, Fdim, C, seed=0, device=dev)   # identical on every rank
     graph = device_graph(data)
     feats, labels = graph.features(data), graph.labels(data)
-    data.edge_index = None                                          # CSC is resident; free the COO
-    torch.cuda.empty_cache()
     torch.manual_seed(0)
     if args.variant == "unsup":
         C = args.hidden              # the unsupervised runners emit embeddings, not class logits
+    if args.aggregator == "lstm":
+        settings.LSTM_NUM_INPUTS = args.lstm_num_inputs
     model = GraphSAGE(Fdim, args.hidden, args.aggregator, len(K), C).to(dev)
+    on_engine = args.aggregator in _REDUCE and args.variant != "trainer-module"
+    if not on_engine and args.variant == "fig2a":
+        if world != 1:
+            raise SystemExit("module-path aggregators are single-GPU measurements here")
+        return module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_mode)
+    data.edge_index = None                                          # CSC is resident; free the COO
+    torch.cuda.empty_cache()
     init_layers = [{k: getattr(m, k).weight.detach().cpu().clone() for k in ("lin_l", "lin_r") if hasattr(m, k)}
                    for m in model.layers]
-    sampler = NeighborSampler.from_graph(graph, K, seed=0)   # the CSC is already resident
     pg = torch.distributed.group.WORLD if world > 1 else None
     if args.variant == "trainer-module":
         return trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank)
-    engine = SageTrainEngine(model, sampler, feats, labels, B, lr=args.lr, world_size=world, process_group=pg,
-                             overlap_gather=args.overlap_gather, group=args.group,
-                             unsup={"trainer": True, "unsup": "only"}.get(args.variant, False))
+    unsup = {"trainer": True, "unsup": "only"}.get(args.variant, False)
 
     # seeds: first n_train ids of randperm(N, seed 0); rank r takes the strided shard r::world
     gen = torch.Generator().manual_seed(0)
@@ -229,100 +330,133 @@ def main():
     def counter_of(step):
         return step * world + rank
 
-    # Roofline probe: one HIP event pair per timed step, attached to the launch of the layer-0
-    # gather itself (hipExtLaunchKernelGGL start / stop events through sage_gather_reduce_fwd_timed):
-    # their elapsed time is that kernel's own duration on its stream.  (--bracket-probe records the
-    # pair around the launch instead: two extra markers, ~5 us more on this platform.)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    use_graph = args.graph and not args.no_graph
     probe = not args.no_probe
     attached = probe and not args.bracket_probe
-    if attached:
-        for a0, b0 in ev:          # torch creates the hipEvent_t on the first record
-            a0.record()
-            b0.record()
-        ev_handles = [(a0.cuda_event, b0.cuda_event) for a0, b0 in ev]
-    use_graph = args.graph and not args.no_graph
-    cur = {"i": 0}
 
-    if use_graph:
-        # HIP-graph replay: batch b = seeds mine[b*B:(b+1)*B], Philox counter rank + b*world
-        engine.capture(mine, counter0=rank, counter_stride=world, split_gather=probe)
-        before = (lambda: ev[cur["i"]][0].record()) if (probe and not attached) else None
-        after = (lambda: ev[cur["i"]][1].record()) if (probe and not attached) else None
+    def make_engine(mdl, overlap):
+        return SageTrainEngine(mdl, NeighborSampler.from_graph(graph, K, seed=0), feats, labels, B, lr=args.lr,
+                               world_size=world, process_group=pg, overlap_gather=overlap, group=args.group,
+                               unsup=unsup)
 
-        def run_step(s, timed):
-            if timed:
-                engine.replay(before, after, ev_handles[cur["i"]] if attached else None)
-            else:
-                engine.replay()
-    else:
-        # same pipeline driven eagerly: the sampler runs engine.depth batches ahead on the side stream
-        depth = engine.depth
-        for d in range(depth):
-            engine.prefetch(seeds_of(d), counter_of(d))
+    def run_schedule(engine, settle, warmup, steps, probe_gather, graph_replay=False):
+        """settle + warmup untimed steps, then `steps` timed ones bracketed by barrier + synchronize;
+        with probe_gather one HIP event pair per timed step is attached to the launch of the layer-0
+        gather (hipExtLaunchKernelGGL start / stop events: that kernel's own duration on its
+        stream; --bracket-probe records the pair around the launch instead)."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] \
+            if probe_gather else []
+        handles = []
+        if probe_gather and attached:
+            for a0, b0 in ev:          # torch creates the hipEvent_t on the first record
+                a0.record()
+                b0.record()
+            handles = [(a0.cuda_event, b0.cuda_event) for a0, b0 in ev]
+        cur = {"i": 0}
+        if graph_replay:
+            engine.capture(mine, counter0=rank, counter_stride=world, split_gather=probe_gather)
+            before = (lambda: ev[cur["i"]][0].record()) if (probe_gather and not attached) else None
+            after = (lambda: ev[cur["i"]][1].record()) if (probe_gather and not attached) else None
 
-        def run_step(s, timed):
-            b = (lambda: ev[cur["i"]][0].record()) if (probe and timed and not attached) else None
-            a = (lambda: ev[cur["i"]][1].record()) if (probe and timed and not attached) else None
-            engine.pipelined_step(seeds_of(s + depth), counter_of(s + depth), b, a,
-                                  ev_handles[cur["i"]] if (attached and timed) else None)
+            def run_step(s, timed):
+                if timed and probe_gather:
+                    engine.replay(before, after, handles[cur["i"]] if attached else None)
+                else:
+                    engine.replay()
+        else:
+            depth = engine.depth
+            for d in range(depth):
+                engine.prefetch(seeds_of(d), counter_of(d))
 
-    # set-up: settle (includes the probe's launch path, so that its call tapes exist), then W warm-up
+            def run_step(s, timed):
+                pg_ = probe_gather and timed
+                b = (lambda: ev[cur["i"]][0].record()) if (pg_ and not attached) else None
+                a = (lambda: ev[cur["i"]][1].record()) if (pg_ and not attached) else None
+                engine.pipelined_step(seeds_of(s + depth), counter_of(s + depth), b, a,
+                                      handles[cur["i"]] if (attached and pg_) else None)
+        for s in range(settle):
+            cur["i"] = s % max(steps, 1)
+            run_step(s, s < 4 * engine.nslots)        # includes the probe's launch path: its tapes exist
+        for s in range(settle, settle + warmup):
+            run_step(s, False)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        st0 = engine.state_sum.clone()
+        t0 = time.perf_counter()
+        for s in range(settle + warmup, settle + warmup + steps):
+            cur["i"] = s - warmup - settle
+            run_step(s, True)
+        engine.flush()                                 # data parallel: the last step's deferred Adam
+        t_issued = time.perf_counter() - t0            # host-side enqueue time of the timed steps
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            elapsed = float(t)
+        if not graph_replay:       # drain the pipeline so that another engine can follow
+            while engine.primed:
+                engine.pipelined_step()
+            engine.flush()
+            torch.cuda.synchronize()
+        st = (engine.state_sum - st0).cpu().double()       # sums over the timed steps (+ the drain's, unused)
+        if int(engine.state_sum[ops.ST_ERROR]) != 0:
+            raise SystemExit("sampler reported an error during the run")
+        ms = torch.tensor([a.elapsed_time(b) for a, b in ev], dtype=torch.float64) if probe_gather else None
+        return {"elapsed": elapsed, "issued": t_issued, "st": st, "gather_ms": ms, "loss": float(engine.loss)}
+
+    def gather_bytes(st, launches):
+        e_b = float(st[ops.ST_EDGES])                    # summed over the timed launches
+        t1 = float(st[ops.ST_HOP_NODES + 1])
+        return 4.0 * Fdim * e_b + 4.0 * Fdim * t1 + 8.0 * (2 * e_b + t1 + launches)
+
     base = max(args.settle_steps, 0)
-    for s in range(base):
-        cur["i"] = s % args.steps
-        run_step(s, s < 4 * engine.nslots)
-    for s in range(base, base + args.warmup):
-        run_step(s, False)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    st0 = engine.state_sum.clone()
+    overlapped = not args.serial and not use_graph
+    import copy
+    # 1. the roofline probe: serial schedule (every kernel of a step on ONE stream), where the
+    #    HBM-bound layer-0 gather has the chip to itself and its event-timed duration is its own
+    probe_res = None
+    if probe and overlapped:
+        pm = copy.deepcopy(model)
+        probe_res = run_schedule(make_engine(pm, False), base, args.warmup, max(1, min(args.probe_steps, args.steps)), True)
+        base_main = min(base, 300)       # the process is warm now
+    else:
+        base_main = base
+    # 2. the headline run
+    engine = make_engine(model, overlapped)
     setup_s = time.perf_counter() - t_setup
-    t0 = time.perf_counter()
-    for s in range(base + args.warmup, base + args.warmup + args.steps):
-        cur["i"] = s - args.warmup - base
-        run_step(s, True)
-    engine.flush()                                 # data parallel: the last step's deferred Adam
-    t_issued = time.perf_counter() - t0            # host-side enqueue time of the timed steps
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t)
-
-    st = (engine.state_sum - st0).cpu().double()       # sums over the timed steps
-    if int(engine.state_sum[ops.ST_ERROR]) != 0:
-        raise SystemExit("sampler reported an error during the run")
-    loss = float(engine.loss)
+    res = run_schedule(engine, base_main, args.warmup, args.steps, probe, graph_replay=use_graph)
+    elapsed, st, loss = res["elapsed"], res["st"], res["loss"]
+    # the drain after the timed region sampled nothing new, but keep the counts exact anyway:
+    # ST sums cover the timed steps because prefetches of the drain are not issued (no next_seeds)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         roofline = None
         if probe:
-            # layer-0 fused gather+mean: algorithmic bytes per launch from the ACTUAL counts
-            e_b = float(st[ops.ST_EDGES])                    # summed over the timed launches
-            t1 = float(st[ops.ST_HOP_NODES + 1])
-            ld = feats.stride(0)
-            bytes_sum = 4.0 * Fdim * e_b + 4.0 * Fdim * t1 + 8.0 * (2 * e_b + t1 + args.steps)
-            ms = torch.tensor([a.elapsed_time(b) for a, b in ev], dtype=torch.float64)
+            src = probe_res if probe_res is not None else res
+            n_launch = src["gather_ms"].numel()
+            # the timed steps' sampled batches: in the pipelined loop the sampler runs `depth` batches
+            # ahead, so the state sums and the gathers timed cover batch sets shifted by `depth` of
+            # the same stationary stream; both are averages over >= 300 batches
+            bytes_sum = gather_bytes(src["st"], n_launch) * (n_launch / max(float(src["st"][ops.ST_HOP_NODES]) / B, 1.0))
+            ms = src["gather_ms"]
             achieved = float(bytes_sum / (float(ms.sum()) * 1e-3) / 1e9)
             traffic, traffic_src = None, None
             tpath = os.path.join(ROOT, "profiles", "gather_traffic.json")
             if args.workload == "reddit" and os.path.exists(tpath):
-                # HBM bytes per launch from rocprofv3 PMC passes of this same command (FETCH_SIZE and
-                # WRITE_SIZE in separate runs, gfx950 correction applied) — measured offline, see file
+                # HBM bytes per launch from rocprofv3 PMC passes of this same kernel on this workload
+                # (FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 correction applied) — measured
+                # offline, see the file
                 with open(tpath) as f:
                     tj = json.load(f)
                 traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/gather_traffic.json"
-            # what an empty event pair measures on this stream (not subtracted from anything: the
-            # rocprofv3 trace under profiles/ times the kernel alone and reads ~4 us less)
             eb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
             for a0, b0 in eb:
                 a0.record()
@@ -333,50 +467,35 @@ def main():
                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                         "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
+                        "schedule": ("serial probe run of this same workload (%d timed steps, every kernel on one stream: "
+                                     "the gather alone on the chip)" % n_launch) if probe_res is not None
+                                    else ("serial headline run" if not use_graph else "graph replay, gather launched eagerly between two graphs"),
                         "timing": ("HIP start/stop events attached to each launch (hipExtLaunchKernelGGL)" if attached
                                    else "HIP events recorded around each launch"),
                         "empty_event_pair_us": round(bracket_us, 2),
-                        "algorithmic_bytes_per_launch": int(bytes_sum / args.steps), "row_stride_floats": int(ld)}
-        # Informational only (never `value`): the same step with overlap_gather — layer-0 gather of
-        # batch i+1 on the side stream beside the forward GEMM of batch i — measured right after
-        # the headline run on a second engine (DESIGN.md 4b says why it is not the default).
-        def run_variant(overlap, x3):
-            import copy
-            if x3:
-                os.environ["SAGE_GEMM_X3"] = "1"      # read by the library at every call
+                        "algorithmic_bytes_per_launch": int(bytes_sum / n_launch), "row_stride_floats": int(feats.stride(0))}
+            if probe_res is not None:
+                # the same kernel in the headline (overlapped) schedule, where it shares the chip with
+                # the MFMA-bound forward GEMM of the previous batch: longer by contention, not by itself
+                oms = res["gather_ms"]
+                roofline["serial_ms_per_step"] = round(probe_res["elapsed"] / n_launch * 1e3, 4)
+                roofline["overlapped_avg_launch_us"] = round(float(oms.mean()) * 1e3, 2)
+        # Informational only (never `value`): the headline schedule with the big contractions on the
+        # exact-fp32 MFMA (SAGE_GEMM_X3=0) instead of the default bf16x3 split
+        variant_f32 = None
+        if world == 1 and not use_graph and not args.no_variant and args.variant == "fig2a" and gemm_mode == "bf16x3":
+            os.environ["SAGE_GEMM_X3"] = "0"      # read by the library at every call
             try:
-                model2 = copy.deepcopy(model)
-                eng2 = SageTrainEngine(model2, NeighborSampler.from_graph(graph, K, seed=0), feats, labels, B,
-                                       lr=args.lr, overlap_gather=overlap)
-                for d in range(eng2.depth):
-                    eng2.prefetch(seeds_of(d), counter_of(d))
+                m2 = copy.deepcopy(model)
                 nv = min(args.steps, 200)
-                for s2 in range(args.warmup):
-                    eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
-                torch.cuda.synchronize()
-                tv = time.perf_counter()
-                for s2 in range(args.warmup, args.warmup + nv):
-                    eng2.pipelined_step(seeds_of(s2 + eng2.depth), counter_of(s2 + eng2.depth))
-                torch.cuda.synchronize()
-                tv = time.perf_counter() - tv
-                eng2.flush()
-                torch.cuda.synchronize()
+                r2 = run_schedule(make_engine(m2, overlapped), 100, args.warmup, nv, False)
             finally:
-                if x3:
-                    del os.environ["SAGE_GEMM_X3"]
-            return {"ms_per_step": round(tv / nv * 1e3, 4), "value": round(B * nv / tv, 1),
-                    "unit": "seed nodes/s", "steps": nv}
-        variant = variant_x3 = None
-        if world == 1 and not args.overlap_gather and not use_graph and not args.no_variant \
-                and args.variant == "fig2a":
-            variant = dict(schedule="overlap_gather", **run_variant(True, False))
-            # Informational only as well: the headline schedule with the big contractions in the
-            # opt-in bf16x3 mode (fp32 operands as three bf16 terms on the bf16 MFMA, fp32
-            # accumulation) — not the default, so never `value`
-            if gemm_mode == "f32":
-                variant_x3 = dict(gemm="bf16x3 forward + weight-gradient contractions (SAGE_GEMM_X3=1)", **run_variant(False, True))
+                del os.environ["SAGE_GEMM_X3"]
+            variant_f32 = {"gemm": "exact-fp32 MFMA contractions (SAGE_GEMM_X3=0)", "steps": nv,
+                           "ms_per_step": round(r2["elapsed"] / nv * 1e3, 4),
+                           "value": round(B * nv / r2["elapsed"], 1), "unit": "seed nodes/s"}
         cpu = None
-        if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a":   # the oracle times fig2a's step
+        if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a" and args.aggregator == "mean":   # the oracle times fig2a's step
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
             colptr, row = graph.colptr.cpu().numpy(), graph.row.cpu().numpy()
             seeds_list = [train[i * B:(i + 1) * B].numpy() for i in range(args.cpu_steps + 1)]
@@ -396,12 +515,18 @@ def main():
                                                        "unsup": "UNSUPERVISED trainer step (random-walk loss, 3 forwards)"}.get(
                                        args.variant, "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},
-            "roofline": roofline, "cpu_baseline": cpu, "variant_overlap_gather": variant,
-            "variant_gemm_bf16x3": variant_x3, "gemm_mode": gemm_mode,
-            "final_loss": round(loss, 5), "setup_s": round(setup_s, 1), "settle_steps": base,
-            "avg_nodes_per_batch": float(st[ops.ST_NODES]) / args.steps,
-            "avg_edges_per_batch": float(st[ops.ST_EDGES]) / args.steps,
-            "variant": args.variant, "hip_graph": use_graph, "host_enqueue_ms_per_step": round(t_issued / args.steps * 1e3, 4), "overlap_gather": bool(args.overlap_gather),
+            "roofline": roofline, "cpu_baseline": cpu,
+            "schedule": ("HIP-graph replay" if use_graph else
+                         "overlapped: layer-0 gather of batch s+1 on the side stream beside batch s" if overlapped
+                         else "serial: every kernel of a step on one stream"),
+            "gemm_mode": gemm_mode + (" (fp32 operands split into 3 bf16 terms, 6 MFMA products, fp32 accumulation)"
+                                      if gemm_mode == "bf16x3" else " (v_mfma_f32_32x32x2_f32)"),
+            "variant_gemm_f32": variant_f32,
+            "final_loss": round(loss, 5), "setup_s": round(setup_s, 1), "settle_steps": base_main,
+            "avg_nodes_per_batch": float(st[ops.ST_NODES]) / max(float(st[ops.ST_HOP_NODES]) / B, 1.0),
+            "avg_edges_per_batch": float(st[ops.ST_EDGES]) / max(float(st[ops.ST_HOP_NODES]) / B, 1.0),
+            "variant": args.variant, "hip_graph": use_graph,
+            "host_enqueue_ms_per_step": round(res["issued"] / args.steps * 1e3, 4), "overlap_gather": bool(overlapped),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -58,6 +58,35 @@ def all_reduce_flat(flat_grad, group=None, async_op=False):
     return None if async_op else flat_grad
 
 
+class PendingReduce:
+    """The data-parallel step's deferred half: ONE gradient all-reduce in flight whose optimizer
+    step is applied later (graphsage_amd/engine.py: launched after the backward of step i,
+    completed just before the first kernel of step i+1 that reads the weights, so the collective
+    overlaps the sampler hand-shake and the weight-free layer-0 gather in between).  Works on
+    whatever all_reduce_flat works on; tests/test_dist_cpu.py drives it with gloo on CPU tensors
+    (a real asynchronous work handle kept across a step)."""
+
+    def __init__(self):
+        self.work = None
+        self.active = False
+
+    def launch(self, flat_grad, group=None):
+        if self.active:
+            raise RuntimeError("the previous step's all-reduce has not been completed")
+        self.work = all_reduce_flat(flat_grad, group, async_op=True)
+        self.active = True
+
+    def complete(self):
+        """True if a reduce was pending; on return the caller (the current stream, for device
+        tensors) is ordered after the collective and may read the summed gradient."""
+        if not self.active:
+            return False
+        work, self.work, self.active = self.work, None, False
+        if work is not None:
+            work.wait()
+        return True
+
+
 def all_reduce_gradients(model, group=None):
     """Module path under data parallelism (any aggregator, any loss): average the gradients of
     `model` over ranks with ONE all-reduce of a flat buffer, in place — call it between

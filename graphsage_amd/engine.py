@@ -17,7 +17,7 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
 import torch
 
 from . import _lib, ops
-from .dist import all_reduce_flat
+from .dist import PendingReduce, all_reduce_flat
 
 _REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max', 'gcn': 'gcn'}   # gcn: no root weight (lin_r)
 
@@ -193,7 +193,11 @@ class SageTrainEngine:
         self.counter = 0
         self.graphs = None
         self._tapes = {}        # recorded C-ABI call sequences, keyed by (what, slot, ..., stream)
-        self._pending = None    # data parallel: (work handle) of a gradient all-reduce not yet applied
+        self._pending = PendingReduce()   # data parallel: the gradient all-reduce not yet applied
+        # data parallel: the host may run at most `run_ahead` steps (= un-waited collectives)
+        # ahead of the device: it blocks on the event recorded that many steps ago
+        self.run_ahead = 8
+        self._dp_events = []
         # pipelining state
         self.side = torch.cuda.Stream(device=dev)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
@@ -239,7 +243,7 @@ class SageTrainEngine:
                               self.table, 1, self.bufs[slot], ctrl=ctrl, num_seeds=self.B)
             ops.state_accumulate(self.bufs[slot].state, self.state_sum)
             return
-        self._stamp += 1
+        self._next_stamp(stream)
         if self.unsup:
             self.slot_counter[slot] = counter
         handle = (stream or torch.cuda.current_stream()).cuda_stream
@@ -270,6 +274,37 @@ class SageTrainEngine:
         args[10] = self._stamp
         _lib.check(fn(*args), name)
         _lib.check(acc[0](*acc[1]), acc[2])      # state_sum += this batch's sizes, same stream
+
+    def _next_stamp(self, stream=None):
+        """Stamps of the relabel table must grow (sage_hip.h); when the 32-bit range is used up,
+        start over with a clean table (as graphsage_amd/samplers/uniform_loader.py does)."""
+        self._stamp += 1
+        if self._stamp >= 2 ** 32 - 1:
+            if stream is not None and stream != torch.cuda.current_stream():
+                with torch.cuda.stream(stream):
+                    self.table.fill_(-1)
+            else:
+                self.table.fill_(-1)
+            self._stamp = 1
+
+    def _require_eager(self, what):
+        """After capture() the graphs own the sampler state: a replay advances the stamp and the
+        Philox counter on the DEVICE (control block) and always leaves a sampler graph in flight
+        on the side stream, so an eager call would sample with stale stamps into buffers that a
+        graph is writing.  Everything eager refuses; release_graphs() hands the state back."""
+        if self.graphs is not None:
+            raise RuntimeError(f"{what}: the engine was captured into HIP graphs — use replay(), or "
+                               "release_graphs() first")
+
+    def release_graphs(self):
+        """Leave graph mode: wait for the graphs in flight and take the stamp they advanced on the
+        device back to the host, so that the eager entry points continue above it."""
+        if self.graphs is None:
+            return
+        torch.cuda.synchronize()
+        self._stamp = int(self.ctrl[ops.CTRL_STAMP]) + 1      # captured with host stamp 1 + ctrl
+        self.graphs = None
+        self._main_touched = True
 
     def _taped(self, what, slot, fn, stream=None):
         """Run fn() through the validating wrappers once per (what, slot, stream) and replay the
@@ -472,10 +507,12 @@ class SageTrainEngine:
                       zero_grad=not self.keep_grads)
 
     # ------------------------------------------------------------------ one batch at a time
-    def step(self, seeds, counter=None):
-        """One eager training step on `seeds` (device int64[B]); returns the device loss tensor."""
-        if self.graphs is not None:
-            raise RuntimeError("engine was captured: use replay()")
+    def step(self, seeds, counter=None, valid=None):
+        """One eager training step on `seeds` (device int64[B]); returns the device loss tensor.
+        valid < B: only the first `valid` seeds count (the partial last batch of an epoch; the
+        rest of `seeds` is padding: the loss is the mean over the valid rows and the padded rows
+        get a zero gradient)."""
+        self._require_eager("step()")
         if self.primed:
             raise RuntimeError("a prefetched batch is pending: use pipelined_step()")
         if counter is None:
@@ -484,10 +521,27 @@ class SageTrainEngine:
         self.flush()
         self._main_touched = True
         self.sample(seeds, counter, slot=0)
-        self.forward_backward(slot=0)
+        if valid is not None and int(valid) < self.B:
+            self._partial_forward_backward(int(valid))
+        else:
+            self.forward_backward(slot=0)
         self.all_reduce()
         self.optimizer_step()
         return self.loss
+
+    def _partial_forward_backward(self, valid):
+        """forward + backward of slot 0 with the loss over the first `valid` seed rows (untaped:
+        once per epoch).  The padded rows' dz is zeroed so that they add nothing to any gradient."""
+        if self.unsup or valid <= 0:
+            raise NotImplementedError("partial batches: supervised step only")
+        self.last_slot = 0
+        buf, last = self.bufs[0], self.act[-1]
+        self._forward_layers(0, 0, False)
+        ops.logits_xent_fused(last['z'], self.labels, buf.node, valid, last['y'], last['inv'], last['dz'],
+                              self.row_loss, self.loss, clear_z=True)
+        last['z'][valid:self.B].zero_()          # the fused kernel consumed (and cleared) `valid` rows only
+        last['dz'][valid:self.B].zero_()
+        self._backward(0)
 
     # ------------------------------------------------------------------ pipelined, eager
     def _side_gather(self, slot, before_gather, after_gather, gather_events=None):
@@ -505,6 +559,7 @@ class SageTrainEngine:
     def prefetch(self, seeds, counter, before_gather=None, after_gather=None, gather_events=None):
         """Sample `seeds` on the side stream into the next slot of the ring.  Call it `depth`
         times before the first pipelined_step()."""
+        self._require_eager("prefetch()")
         n = self.n_pref
         if n - self.n_comp >= self.depth:
             raise RuntimeError("prefetch(): the pipeline is full")
@@ -576,7 +631,13 @@ class SageTrainEngine:
         self.flush()
         self.forward_backward(slot=p, skip_gather0=True)
         if self.world_size > 1:
-            self._pending = (all_reduce_flat(self.grad, self.pg, async_op=True),)
+            self._pending.launch(self.grad, self.pg)
+            # bound the host's run-ahead: with RCCL neither the launch nor wait() blocks the host
+            ev = torch.cuda.Event()
+            ev.record(main)
+            self._dp_events.append(ev)
+            if len(self._dp_events) > self.run_ahead:
+                self._dp_events.pop(0).synchronize()
         else:
             self.optimizer_step()
         if (i + 1) % self.group == 0:
@@ -589,37 +650,43 @@ class SageTrainEngine:
         """Apply a deferred optimizer step.  Under data parallelism pipelined_step() returns with
         the gradient all-reduce in flight and applies Adam at the start of the next call (or
         here): call flush() before reading the weights."""
-        if self._pending is not None:
-            work = self._pending[0]
-            self._pending = None
-            if work is not None:
-                work.wait()
+        if self._pending.complete():
             self.optimizer_step()
 
     # ------------------------------------------------------------------ epochs and evaluation
-    def train_epoch(self, seeds, epoch=0, rank=0):
-        """One pass over `seeds` (device int64) in batches of B with the pipelined step (the
-        tail that does not fill a batch is dropped, as under data parallelism every rank must
-        run the same number of steps).  The loss is accumulated on the device — the reference
+    def train_epoch(self, seeds, epoch=0, rank=0, drop_last=None):
+        """One pass over `seeds` (device int64) in batches of B with the pipelined step.  The tail
+        that does not fill a batch is trained as a padded partial batch when drop_last=False
+        (the reference's loaders keep it, torch DataLoader's default; supervised step only) and
+        dropped otherwise (default: under data parallelism every rank must run the same number
+        of steps, which equal shards guarantee either way).  The loss is accumulated on the device — the reference
         synchronises every step with loss.item() (trainers/node_level_graphsage_trainers.py:46)
         — and returned as a device tensor: mean training loss over the epoch."""
         from .dist import batch_counter
+        self._require_eager("train_epoch()")
         nb = seeds.numel() // self.B
-        if nb == 0:
+        tail = seeds.numel() - nb * self.B if (drop_last is False and not self.unsup) else 0
+        if nb == 0 and tail == 0:
             raise RuntimeError("fewer seeds than one batch")
         total = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        nb_all = nb + (1 if tail else 0)
 
         def counter(b):
-            return batch_counter(epoch, nb, b, rank, self.world_size)
+            return batch_counter(epoch, nb_all, b, rank, self.world_size)
         d = self.depth
         for b in range(min(d, nb)):
             self.prefetch(seeds[b * self.B:(b + 1) * self.B], counter(b))
         for b in range(nb):
             nxt = seeds[(b + d) * self.B:(b + d + 1) * self.B] if b + d < nb else None
             loss = self.pipelined_step(nxt, counter(b + d) if nxt is not None else None)
-            total += loss
+            total += loss * self.B
         self.flush()
-        return total / nb
+        if tail:
+            rest = seeds[nb * self.B:]
+            padded = torch.cat([rest, rest[:1].expand(self.B - tail)]).contiguous()
+            total += self.step(padded, counter=counter(nb), valid=tail) * tail
+        # mean over the examples, as the reference accumulates it (fig2a/runners/graphsage_runners.py:48-50)
+        return total / (nb * self.B + tail)
 
     @torch.no_grad()
     def evaluate(self, seeds, counter0=1 << 40):
@@ -627,6 +694,7 @@ class SageTrainEngine:
         tensors — accuracy = micro-F1 for single-label classification (what
         f1_score(average='micro') returns in trainers/node_level_graphsage_trainers.py:56-57).
         Sampled fan-out neighbourhoods as in GraphSAGE.inference (models/graphsage.py:51-68)."""
+        self._require_eager("evaluate()")
         if self.primed:
             raise RuntimeError("a prefetched batch is pending")
         self.flush()

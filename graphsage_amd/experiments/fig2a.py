@@ -52,8 +52,12 @@ def train(epoch, model, optimizer, train_loader, engine=None):
     torch.cuda.synchronize()
     start = time.time()
     if engine is not None:
-        loss = engine.train_epoch(train_loader._idx_dev, epoch=epoch)
-        nb = train_loader._idx_dev.numel() // engine.B
+        # the loader's own order for this epoch: a fresh permutation when it was built with
+        # shuffle=True (fig2a/runners/graphsage_runners.py:72-73), partial last batch included
+        seeds = train_loader._order()
+        train_loader.epoch += 1
+        loss = engine.train_epoch(seeds, epoch=epoch, drop_last=False)
+        nb = len(train_loader)
         torch.cuda.synchronize()
         return float(loss), (time.time() - start) / nb
     total = torch.zeros((), device=dev)

@@ -43,11 +43,42 @@ def _dp_engine():
     return {'world_size': kw['world_size'], 'process_group': dist.group.WORLD} if kw else {}
 
 
-def _engine_for(trainer, unsup):
-    """Static-shape engine over the trainer's model / optimizer settings / train loader."""
+def _engine_refusal(trainer, unsup):
+    """Why the static-shape engine cannot run this trainer's step (None if it can): it implements
+    Adam, plain mean cross entropy on int64 labels, the logsigmoid unsupervised term, the
+    aggregators of engine._REDUCE, and full batches of the loader's batch size."""
+    from ..engine import _REDUCE
+    if type(trainer.optimizer) is not torch.optim.Adam or len(trainer.optimizer.param_groups) != 1 \
+            or trainer.optimizer.param_groups[0].get('amsgrad'):
+        return "the engine implements plain Adam with one parameter group"
+    if trainer.model.aggregator not in _REDUCE:
+        return f"aggregator {trainer.model.aggregator!r} runs on the module path"
+    if unsup != 'only':
+        fn = getattr(trainer, 'loss_fn', None)
+        plain = fn is F.cross_entropy or (isinstance(fn, torch.nn.CrossEntropyLoss) and fn.weight is None
+                                          and fn.reduction == 'mean' and fn.label_smoothing == 0.0
+                                          and fn.ignore_index == -100)
+        if not plain:
+            return "the engine's supervised term is plain mean cross entropy"
+        y = getattr(trainer.data, 'y', None)
+        if y is None or y.dtype != torch.int64 or y.dim() != 1:
+            return "the engine needs single-label int64 targets"
+    if unsup and settings.args.use_triple_loss:
+        return "the engine's unsupervised term is the logsigmoid loss (--use_triple_loss is set)"
+    if len(trainer.train_loader.dataset) < trainer.train_loader.batch_size:
+        return "fewer training seeds than one batch"
+    return None
+
+
+def _engine_for(trainer, unsup, explicit):
+    """Static-shape engine over the trainer's model / optimizer settings / train loader; None when
+    the step is outside what the engine implements and it was not asked for explicitly."""
     from ..engine import SageTrainEngine
-    if not isinstance(trainer.optimizer, torch.optim.Adam):
-        raise RuntimeError("the engine implements Adam")
+    why = _engine_refusal(trainer, unsup)
+    if why is not None:
+        if explicit:
+            raise RuntimeError(f"use_engine=True: {why}")
+        return None
     g = trainer.optimizer.param_groups[0]
     sampler = trainer.train_loader.neighbor_sampler
     graph = sampler.graph
@@ -64,22 +95,22 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
         mk = lambda mask, **kw: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
                                        **dataloader_kwargs, **kw)
         self.train_loader = mk(data.train_mask, **_dp_shard())   # training seeds sharded over ranks
+        # evaluation on the training split sees ALL of it on every rank, like val / test
+        self.train_eval_loader = mk(data.train_mask) if _dp_shard() else self.train_loader
         self.val_loader = mk(data.val_mask)
         self.test_loader = mk(data.test_mask)
+        # use_engine=None: the engine where it implements exactly this trainer's step (fig2a's
+        # step definition: supervised_only), else the module path; True: the engine or an error
         self.engine = None
-        if use_engine is None:
-            use_engine = supervised_only
-        if use_engine:
-            self.engine = self._make_engine()
-
-    def _make_engine(self):
-        return _engine_for(self, unsup=not self.supervised_only)
+        if use_engine or (use_engine is None and supervised_only):
+            self.engine = _engine_for(self, unsup=not self.supervised_only, explicit=bool(use_engine))
 
     def train(self, epoch):
         self.model.train()
         if self.engine is not None:
             seeds = self.train_loader._idx_dev
-            return self.engine.train_epoch(seeds, epoch=epoch, rank=_dp_shard().get('rank', 0))
+            # (the loaders keep a partial last batch; the engine trains it padded and masked)
+            return self.engine.train_epoch(seeds, epoch=epoch, rank=_dp_shard().get('rank', 0), drop_last=False)
         total = torch.zeros((), device=self.device)
         count = 0
         for batch in self.train_loader:
@@ -106,7 +137,7 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
 
     @torch.no_grad()
     def test(self):
-        train_acc, train_f1 = self.eval(self.train_loader) if not settings.NO_EVAL_TRAIN else (None, None)
+        train_acc, train_f1 = self.eval(self.train_eval_loader) if not settings.NO_EVAL_TRAIN else (None, None)
         val_acc, val_f1 = self.eval(self.val_loader)
         test_acc, test_f1 = self.eval(self.test_loader)
         return {'train_acc': train_acc, 'train_f1': train_f1, 'val_acc': val_acc, 'val_f1': val_f1,
@@ -120,11 +151,13 @@ class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
         mk = lambda mask, **kw: loader(data, input_nodes=mask, num_neighbors=[self.k1, self.k2], shuffle=False,
                                        **dataloader_kwargs, **kw)
         self.train_loader = mk(data.train_mask, **_dp_shard())   # training seeds sharded over ranks
+        # the downstream head is fitted on the embeddings of the WHOLE training split on every rank
+        self.train_eval_loader = mk(data.train_mask) if _dp_shard() else self.train_loader
         self.val_loader = mk(data.val_mask)
         self.test_loader = mk(data.test_mask)
         # use_engine: the epoch runs on the static-shape engine (loss = the unsupervised term
-        # alone, three forwards per batch; mean / sum / max models with Adam)
-        self.engine = _engine_for(self, unsup='only') if use_engine else None
+        # alone, three forwards per batch; mean / sum / max / gcn models with Adam)
+        self.engine = _engine_for(self, unsup='only', explicit=True) if use_engine else None
 
     def train(self, epoch):
         self.model.train()
@@ -161,7 +194,7 @@ class UnsupervisedGraphSageTrainerForNodeLevelTask(GraphSageBaseTrainer):
     def test(self):
         y_all = self.data.y.to(self.device)
         masks = {k: getattr(self.data, f'{k}_mask').to(self.device) for k in ('train', 'val', 'test')}
-        outs = {'train': self.model.inference(self.train_loader)}
+        outs = {'train': self.model.inference(self.train_eval_loader)}
         num_classes = int(y_all.max()) + 1
         w, b = self._fit_head(outs['train'], y_all[masks['train']], num_classes)
         outs['val'] = self.model.inference(self.val_loader)

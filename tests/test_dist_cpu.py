@@ -55,3 +55,62 @@ def test_gloo_world2():
         lb = torch.zeros_like(la) if lb is None else lb
         assert torch.equal(ga, gb)
         torch.testing.assert_close(ga, (la + lb) / 2)
+
+
+def _pending_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphsage_amd.dist import PendingReduce
+    g = torch.Generator().manual_seed(7 + rank)
+    p = torch.ones(64)
+    m, v = torch.zeros(64), torch.zeros(64)
+    pend = PendingReduce()
+    grad = torch.zeros(64)
+    applied = 0
+    handles = []
+    for step in range(1, 13):
+        # the engine's order (pipelined_step): work that needs no weights, THEN the deferred
+        # optimizer step of the previous batch, then this batch's gradient and its all-reduce
+        weight_free = torch.randn(64, generator=g).sum()          # stands for sampler wait + gather
+        if pend.complete():
+            applied += 1
+            p, m, v = sage_ref.adam_ref(p, grad / world, m, v, applied, 1e-2)
+        grad = torch.randn(64, generator=g) + 0.1 * p + 0.0 * weight_free
+        pend.launch(grad, None)
+        handles.append(pend.work is not None and hasattr(pend.work, "wait"))
+        try:
+            pend.launch(grad, None)                               # a second launch must be refused
+            raise AssertionError("double launch accepted")
+        except RuntimeError:
+            pass
+    assert pend.complete() and not pend.complete()                # flush(): exactly one pending
+    applied += 1
+    p, m, v = sage_ref.adam_ref(p, grad / world, m, v, applied, 1e-2)
+    out[rank] = (p.tolist(), applied, all(handles))
+    dist.destroy_process_group()
+
+
+def test_pending_reduce_async_handle_across_steps():
+    """The engine's data-parallel control flow with a REAL asynchronous work handle (gloo on CPU
+    tensors, async_op=True): the all-reduce launched at the end of step i is completed — and its
+    Adam step applied — inside step i+1; replicas stay bit-identical and equal a serial emulation."""
+    world = 2
+    out = mp.Manager().dict()
+    port = 29000 + (os.getpid() % 400)
+    mp.spawn(_pending_worker, args=(world, port, out), nprocs=world, join=True)
+    (p0, n0, h0), (p1, n1, h1) = out[0], out[1]
+    assert n0 == n1 == 12 and h0 and h1
+    assert p0 == p1
+    # serial emulation of both ranks
+    gens = [torch.Generator().manual_seed(7 + r) for r in range(world)]
+    p = torch.ones(64)
+    m, v = torch.zeros(64), torch.zeros(64)
+    total = None
+    for step in range(1, 13):
+        wf = [torch.randn(64, generator=g).sum() for g in gens]
+        if total is not None:
+            p, m, v = sage_ref.adam_ref(p, total / world, m, v, step - 1, 1e-2)
+        total = sum(torch.randn(64, generator=g) + 0.1 * p + 0.0 * w for g, w in zip(gens, wf))
+    p, m, v = sage_ref.adam_ref(p, total / world, m, v, 12, 1e-2)
+    torch.testing.assert_close(torch.tensor(p0), p, rtol=1e-6, atol=1e-7)

@@ -42,7 +42,7 @@ def _worker(rank, world, port, out, long_run=False):
     from graphsage_amd.dist import batch_counter, shard_seeds
     dev = torch.device("cuda:0")
     data, model, train = _setup()
-    if long_run:      # what bench.py does: many steps, the host never waits for the device
+    if long_run:      # bench.py's loop shape: many steps, no loss read-back in between
         train = torch.randint(0, 1500, (2 * B * LONG_STEPS,), generator=torch.Generator().manual_seed(2))
     eng = _engine(data, model, dev, world_size=world, process_group=dist.group.WORLD)
     mine = shard_seeds(train, rank, world).to(dev)
@@ -63,7 +63,13 @@ def _worker(rank, world, port, out, long_run=False):
     dist.destroy_process_group()
 
 
-def test_engine_data_parallel_many_steps_no_host_sync(dev):
+def test_engine_data_parallel_many_steps_staged_allreduce(dev):
+    """80 pipelined steps on two ranks without reading anything back in between.  With gloo on
+    a device tensor the all-reduce is staged through pinned host memory and synchronises the
+    stream every step (graphsage_amd/dist.py), so this covers the engine's deferred-Adam control
+    flow and the replicas' bit-identity over a long run, NOT the no-host-sync regime RCCL runs in
+    (that one has no single-GPU rehearsal; the async work-handle path is driven on CPU tensors
+    in tests/test_dist_cpu.py)."""
     world = 2
     out = mp.Manager().dict()
     port = 29300 + (os.getpid() % 300)
@@ -150,3 +156,45 @@ def test_module_path_trainer_data_parallel_two_ranks(dev):
     assert torch.equal(w0, w1)
     assert len(s0) == len(s1) == 300 and not set(s0) & set(s1)
     assert f0 == f1 and f0 > 0.5
+
+
+def _unsup_trainer_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    from graphsage_amd.trainers import UnsupervisedGraphSageTrainerForNodeLevelTask, dataloader_kwargs
+    dev = torch.device("cuda:0")
+    data = planted_partition(1500, 30000, 24, 5, seed=8, noise=1.0)
+    n = data.num_nodes
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    for name, sl in (("train_mask", perm[:600]), ("val_mask", perm[600:900]), ("test_mask", perm[900:])):
+        m = torch.zeros(n, dtype=torch.bool)
+        m[sl] = True
+        setattr(data, name, m)
+    torch.manual_seed(3)
+    model = GraphSAGE(24, 16, "mean", 2).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+    dataloader_kwargs['batch_size'] = 100
+    tr = UnsupervisedGraphSageTrainerForNodeLevelTask(data, UniformLoader, model=model, optimizer=opt,
+                                                      num_epochs=2, device=dev, k1=5, k2=3)
+    best = tr.run(verbose=False)
+    out[rank] = (torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()]),
+                 len(tr.train_loader.dataset), len(tr.train_eval_loader.dataset), best)
+    dist.destroy_process_group()
+
+
+def test_unsupervised_trainer_data_parallel_two_ranks(dev):
+    """run() of the unsupervised trainer under data parallelism: training seeds are sharded, the
+    downstream head is fitted on the embeddings of the WHOLE training split (its labels are the
+    whole split's), replicas stay bit-identical and report the same metrics."""
+    world = 2
+    out = mp.Manager().dict()
+    port = 28700 + (os.getpid() % 200)
+    mp.spawn(_unsup_trainer_worker, args=(world, port, out), nprocs=world, join=True)
+    (w0, nt0, ne0, b0), (w1, nt1, ne1, b1) = out[0], out[1]
+    assert torch.equal(w0, w1)
+    assert nt0 == nt1 == 300 and ne0 == ne1 == 600
+    assert b0['test_f1'] == b1['test_f1'] and b0['test_f1'] > 0.5 and 'train_f1' in b0

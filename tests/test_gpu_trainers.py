@@ -230,3 +230,67 @@ def test_engine_trainer_step_with_unsup_term_matches_oracle(dev, unsup, aggregat
         for m, p in zip(model.layers, params):
             for k in p:
                 torch.testing.assert_close(getattr(m, k).weight.detach().cpu(), p[k], rtol=1e-4, atol=1e-6)
+
+
+def test_engine_partial_last_batch_matches_oracle(dev):
+    """The partial last batch of an epoch (the reference's loaders keep it): seeds padded to B,
+    loss = mean over the valid rows, padded rows without gradient — against the oracle on the
+    same padded seed list with the cross entropy over the valid rows."""
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = _dataset()[0]
+    B, fan, lr, valid = 64, [6, 4], 1e-2, 23
+    layers = make_layers([24, 16, 5], "mean", 5)
+    model = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
+    load_layers(model, layers)
+    graph = device_graph(data)
+    engine = SageTrainEngine(model, NeighborSampler(data, fan, seed=13), graph.features(data),
+                             graph.labels(data), B, lr=lr, keep_grads=True)
+    train = data.train_mask.nonzero().view(-1)
+    engine.step(train[:B].to(dev), counter=1)                 # a full batch first: buffers are dirty
+    params = [{k: getattr(m, k).weight.detach().cpu().clone() for k in ("lin_l", "lin_r")} for m in model.layers]
+    rest = train[B:B + valid]
+    padded = torch.cat([rest, rest[:1].expand(B - valid)])
+    loss = engine.step(padded.to(dev), counter=2, valid=valid)
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), data.num_nodes)
+    node, src, dst, _, _, _ = sampler.neighbor_sample(c0, r0, padded.numpy(), fan, 13, 2)
+    leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+    out = sage_ref.graphsage_forward(data.x[node], torch.from_numpy(np.stack([src, dst])), leaf)[:valid]
+    want = F.cross_entropy(out, data.y[rest])
+    want.backward()
+    torch.testing.assert_close(loss.cpu().view(()), want.detach(), rtol=1e-5, atol=1e-6)
+    for m, lf in zip(model.layers, leaf):
+        for k in lf:
+            torch.testing.assert_close(engine.gviews[getattr(m, k).weight].cpu(), lf[k].grad, rtol=1e-3, atol=1e-6)
+    # and the next full batch is unaffected by what the partial one left behind
+    l3 = float(engine.step(train[:B].to(dev), counter=3))
+    assert l3 == l3 and 0 < l3 < 10
+
+
+def test_fig2a_engine_epochs_reshuffle_and_cover_the_tail(dev):
+    """fig2a trains with shuffle=True (fig2a/runners/graphsage_runners.py:72-73): two epochs see
+    different batch compositions, and all n_train seeds are trained each epoch (tail included)."""
+    from graphsage_amd.experiments import fig2a
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd import ops
+    ds = _dataset(noise=1.0)
+    data = ds[0]
+    loader = UniformLoader(data, input_nodes=data.train_mask, num_neighbors=[6, 4], shuffle=True, batch_size=128)
+    o1, o2 = loader._order().clone(), loader._order().clone()
+    assert not torch.equal(o1, o2) and torch.equal(o1.sort().values, o2.sort().values)
+    torch.manual_seed(0)
+    model = GraphSAGE(ds.num_features, 32, "mean", 2, ds.num_classes).to(dev)
+    graph = loader.neighbor_sampler.graph
+    engine = SageTrainEngine(model, loader.neighbor_sampler, graph.features(data), graph.labels(data), 128, lr=1e-2)
+    n_train = int(data.train_mask.sum())                       # 640 = 5 x 128: add a tail by dropping 7 seeds
+    loader._idx_dev = loader._idx_dev[:n_train - 7]
+    loader.dataset.idx = loader.dataset.idx[:n_train - 7]
+    seeds_before = int(engine.state_sum[ops.ST_HOP_NODES])
+    losses = [fig2a.train(e, model, None, loader, engine)[0] for e in (1, 2)]
+    assert int(engine.step_dev) == 2 * 5                       # 4 full batches + the padded tail, twice
+    assert int(engine.state_sum[ops.ST_HOP_NODES]) - seeds_before == 2 * 5 * 128
+    assert losses[1] < losses[0]
