@@ -1,0 +1,11 @@
+"""Top-level `samplers` as the reference's scripts spell it when run with graphsage/ on the path
+(see compat/graphsage/__init__.py); everything comes from graphsage_amd.samplers."""
+import importlib
+import sys
+
+from graphsage_amd.samplers import *  # noqa: F401,F403
+from graphsage_amd import samplers as _impl
+
+for _sub in ('uniform_loader', 'utils'):
+    sys.modules[f"{__name__}.{_sub}"] = importlib.import_module(f"graphsage_amd.samplers.{_sub}")
+__all__ = getattr(_impl, "__all__", [n for n in dir(_impl) if not n.startswith("_")])

@@ -77,3 +77,46 @@ class Data:
             v = self.__dict__[k]
             parts.append(f"{k}={list(v.shape)}" if isinstance(v, torch.Tensor) else f"{k}={v}")
         return f"{self.__class__.__name__}({', '.join(parts)})"
+
+
+def collate_graphs(graphs):
+    """Several graphs as ONE disconnected graph (what torch_geometric's DataLoader hands to
+    reference trainers/graph_level_graphsage_trainers.py:29-41): node tensors concatenated,
+    edge_index shifted by the node offsets; `batch` maps nodes to graphs, `num_graphs` counts them."""
+    graphs = list(graphs)
+    out = Data()
+    offset, eis, owner = 0, [], []
+    for g, d in enumerate(graphs):
+        eis.append(d.edge_index + offset)
+        owner.append(torch.full((d.num_nodes,), g, dtype=torch.int64))
+        offset += d.num_nodes
+    for key in graphs[0].keys():
+        vals = [getattr(d, key) for d in graphs]
+        if key == "edge_index" or not all(isinstance(v, torch.Tensor) for v in vals):
+            continue
+        if all(v.dim() >= 1 and v.size(0) == d.num_nodes for v, d in zip(vals, graphs)):
+            setattr(out, key, torch.cat(vals, dim=0))
+    out.edge_index = torch.cat(eis, dim=1)
+    out.batch = torch.cat(owner)
+    out.num_graphs = len(graphs)
+    return out
+
+
+class GraphDataLoader:
+    """Iterable of collated graph batches with the two attributes the reference's graph-level
+    trainers read: len(loader.dataset) and batch.num_graphs (the role torch_geometric.loader.
+    DataLoader plays in examples/ppi_graphsage_supervised.py:32-34; absent from this image)."""
+
+    def __init__(self, dataset, batch_size=1, shuffle=False, seed=0, **unused):
+        self.dataset = dataset
+        self.batch_size, self.shuffle = int(batch_size), bool(shuffle)
+        self.generator = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return (len(self.dataset) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        n = len(self.dataset)
+        order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
+        for b in range(0, n, self.batch_size):
+            yield collate_graphs(self.dataset[i] for i in order[b:b + self.batch_size])

@@ -50,7 +50,6 @@ class SampleSizeRunner:
             model = GraphSAGE(in_channels=self.dataset.num_features, hidden_channels=self.hidden_channels,
                               out_channels=self.dataset.num_classes, num_layers=NUM_LAYERS,
                               aggregator=self.aggregator).to(device)
-            engine_ok = self.use_engine and self.aggregator in ('mean', 'sum', 'max', 'gcn')
             best_result, all_results = SupervisedGraphSageTrainerForNodeLevelTask(
                 data, UniformLoader,
                 dataset_name='fig2b',
@@ -61,7 +60,7 @@ class SampleSizeRunner:
                 loss_fn=torch.nn.CrossEntropyLoss(),
                 optimizer=torch.optim.Adam(model.parameters(), lr=self.learning_rate),
                 device=device,
-                use_engine=engine_ok,
+                use_engine='auto' if self.use_engine else False,
             ).run(return_best_epoch_only=False, verbose=self.verbose)
             test_times.append(sum(r['test_time'] for r in all_results) / len(all_results))
             test_f1s.append(best_result['test_f1'])

@@ -3,3 +3,5 @@ from .base_trainers import (BaseTrainer, GraphSageBaseTrainer, SupervisedGraphSa
                             SupervisedTorchModuleBaseTrainer, TorchModuleBaseTrainer, dataloader_kwargs)
 from .node_level_graphsage_trainers import (SupervisedGraphSageTrainerForNodeLevelTask,
                                             UnsupervisedGraphSageTrainerForNodeLevelTask)
+from .graph_level_graphsage_trainers import (SupervisedGraphSageTrainerForGraphLevelTask,
+                                             UnsupervisedGraphSageTrainerForGraphLevelTask)

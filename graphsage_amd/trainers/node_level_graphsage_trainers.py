@@ -101,9 +101,10 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
         self.test_loader = mk(data.test_mask)
         # use_engine=None: the engine where it implements exactly this trainer's step (fig2a's
         # step definition: supervised_only), else the module path; True: the engine or an error
+        # 'auto': the engine whenever it implements this step, silently the module path otherwise
         self.engine = None
         if use_engine or (use_engine is None and supervised_only):
-            self.engine = _engine_for(self, unsup=not self.supervised_only, explicit=bool(use_engine))
+            self.engine = _engine_for(self, unsup=not self.supervised_only, explicit=use_engine is True)
 
     def train(self, epoch):
         self.model.train()

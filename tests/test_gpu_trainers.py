@@ -294,3 +294,88 @@ def test_fig2a_engine_epochs_reshuffle_and_cover_the_tail(dev):
     assert int(engine.step_dev) == 2 * 5                       # 4 full batches + the padded tail, twice
     assert int(engine.state_sum[ops.ST_HOP_NODES]) - seeds_before == 2 * 5 * 128
     assert losses[1] < losses[0]
+
+
+def test_fig2a_reported_accuracy_matches_oracle(dev, monkeypatch):
+    """f-4: what experiments/fig2a reports (test accuracy after its epochs; reference
+    experiments/fig2a/runners/graphsage_runners.py:57-66, :92) against the CPU oracle trained on
+    the same shuffled batches (the loader's own generator), same Philox counters, and evaluated on
+    the same sampled test neighbourhoods: within 0.5 pt."""
+    from graphsage_amd.dist import batch_counter
+    from graphsage_amd.experiments import fig2a
+    from graphsage_amd import settings
+    ds = _dataset(noise=1.5)
+    data = ds[0]
+    B, fan, epochs = 128, [6, 4], 4
+    monkeypatch.setattr(fig2a, "LEARNING_RATE", 1e-2)      # 20 steps must move the model (the harness's 1e-3 is for Reddit-length epochs)
+    torch.manual_seed(11)
+    out = fig2a.get("mean", dataset=ds, num_epochs=epochs, batch_size=B, k1=fan[0], k2=fan[1], verbose=False).run()
+    assert out['engine']
+    # the oracle's replay of that run: same initial weights (same torch seed), same batch order
+    torch.manual_seed(11)
+    from graphsage_amd.models import GraphSAGE
+    init = GraphSAGE(ds.num_features, fig2a.HIDDEN_CHANNELS, "mean", 2, ds.num_classes)
+    layers = [{"lin_l": m.lin_l.weight.detach().clone(), "lin_r": m.lin_r.weight.detach().clone()} for m in init.layers]
+    train = data.train_mask.nonzero().view(-1)
+    gen = torch.Generator().manual_seed(settings.SEED)
+    nb = train.numel() // B
+    assert nb * B == train.numel()
+    batches, counters = [], []
+    for epoch in range(1, epochs + 1):
+        order = train[torch.randperm(train.numel(), generator=gen)]
+        for b in range(nb):
+            batches.append(order[b * B:(b + 1) * B])
+            counters.append(batch_counter(epoch, nb, b, 0, 1))
+    _, params = _oracle_train(data, layers, batches, fan, settings.SEED, counters, fig2a.LEARNING_RATE, B)
+    # fig2a.test() walks the test loader twice per epoch (inference, then the labels): the last
+    # inference pass is the loader's epoch 2 * (epochs - 1)
+    test_ids = data.test_mask.nonzero().view(-1)
+    nb_test = (test_ids.numel() + B - 1) // B
+    acc_ref = _oracle_accuracy(data, params, test_ids, fan, settings.SEED, batch_counter(2 * (epochs - 1), nb_test, 0, 0, 1), B)
+    assert abs(out['test_acc'] - acc_ref) <= 0.005, (out['test_acc'], acc_ref)
+
+
+def test_fig2b_reported_f1_matches_oracle(dev):
+    """f-4: what experiments/fig2b reports for one sample size (test micro-F1 of the trainer's
+    step: cross entropy + unsupervised term, three forwards; reference experiments/fig2b/runners/
+    runners.py:20-57) against the CPU oracle run on the same batches, positives and negatives."""
+    from graphsage_amd.dist import batch_counter
+    from graphsage_amd.experiments import fig2b
+    from graphsage_amd import settings
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.trainers import dataloader_kwargs
+    ds = _dataset(noise=1.5)
+    data = ds[0]
+    s, B, hidden, lr = 5, 128, 32, 1e-2
+    old = dict(dataloader_kwargs)
+    dataloader_kwargs['batch_size'] = B
+    try:
+        torch.manual_seed(5)
+        out = fig2b.get(s, dataset=ds, num_epochs=1, num_runs=1, hidden_channels=hidden, learning_rate=lr).run()
+    finally:
+        dataloader_kwargs.update(old)
+    torch.manual_seed(5)
+    init = GraphSAGE(ds.num_features, hidden, "mean", 2, ds.num_classes)
+    params = [{"lin_l": m.lin_l.weight.detach().clone(), "lin_r": m.lin_r.weight.detach().clone()} for m in init.layers]
+    state = [{k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in p.items()} for p in params]
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), data.num_nodes)
+    train = data.train_mask.nonzero().view(-1)
+    nb = train.numel() // B
+    seed = settings.SEED
+    for b in range(nb):                                   # trainer loaders: shuffle=False, epoch 1
+        seeds, counter = train[b * B:(b + 1) * B], batch_counter(1, nb, b, 0, 1)
+        node, src, dst, _, _, _ = sampler.neighbor_sample(c0, r0, seeds.numpy(), [s, s], seed, counter)
+        pos = sampler.random_neighbor(c0, r0, node, seed, counter)
+        neg = sampler.random_nodes(data.num_nodes, len(node), seed, counter)
+        leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in params]
+        ei = torch.from_numpy(np.stack([src, dst]))
+        outs = [sage_ref.graphsage_forward(data.x[torch.from_numpy(ids)], ei, leaf)[:B] for ids in (node, pos, neg)]
+        loss = sage_ref.unsup_loss(*outs) + F.cross_entropy(outs[0], data.y[seeds])
+        loss.backward()
+        for p, lf, st in zip(params, leaf, state):
+            for k in p:
+                p[k], m1, v1 = sage_ref.adam_ref(p[k], lf[k].grad, st[k][0], st[k][1], b + 1, lr)
+                st[k] = (m1, v1)
+    test_ids = data.test_mask.nonzero().view(-1)
+    f1_ref = _oracle_accuracy(data, params, test_ids, [s, s], seed, 0, B)     # test loader's first pass: epoch 0
+    assert abs(out['test_f1'] - f1_ref) <= 0.005, (out['test_f1'], f1_ref)
