@@ -200,6 +200,12 @@ class SageTrainEngine:
         self._dp_events = []
         # pipelining state
         self.side = torch.cuda.Stream(device=dev)
+        # overlap_gather: the sampler gets a stream of its own.  Its short latency-bound kernels
+        # only find free CU resources between the big kernels (a resident bf16x3 GEMM holds every
+        # VGPR), and on the gather's stream that wait would delay the gather the main stream needs
+        # next; the sampler's result is needed two batches later.
+        self.samp = torch.cuda.Stream(device=dev) if self.overlap_gather else self.side
+        self.sampled = [torch.cuda.Event() for _ in range(self.nslots)]     # slot sampled (sampler stream)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
         self.cons_ev = [torch.cuda.Event(), torch.cuda.Event()]   # main stream finished a group
         self.started = torch.cuda.Event()    # main stream reached the start of a step
@@ -545,6 +551,7 @@ class SageTrainEngine:
 
     # ------------------------------------------------------------------ pipelined, eager
     def _side_gather(self, slot, before_gather, after_gather, gather_events=None):
+        self.side.wait_event(self.sampled[slot])      # the sampler runs on a stream of its own
         if before_gather is None and after_gather is None:
             self.gather_layer0(slot, stream=self.side, events=gather_events)
         else:     # the hooks record events on the current stream
@@ -569,14 +576,16 @@ class SageTrainEngine:
         if n < self.nslots or need > self.cons_rec_seq or self._main_touched:
             # first use of the slot, serial step()/evaluate() calls in between, or an irregular
             # call sequence that no recorded event covers
-            self.side.wait_stream(main)
+            self.samp.wait_stream(main)
             self.side_cons_seq = self.n_comp - 1
             self._main_touched = False
         elif need > self.side_cons_seq:
-            self.side.wait_event(self.cons_latest)      # once per group in steady state
+            self.samp.wait_event(self.cons_latest)      # once per group in steady state
             self.side_cons_seq = self.cons_rec_seq
-        self.sample(seeds, counter, slot=slot, stream=self.side)
-        seeds.record_stream(self.side)
+        self.sample(seeds, counter, slot=slot, stream=self.samp)
+        seeds.record_stream(self.samp)
+        if self.overlap_gather:
+            self.sampled[slot].record(self.samp)
         self.gathered[slot] = False
         self.n_pref = n + 1
         if not self.overlap_gather:

@@ -148,13 +148,12 @@ int sage_ctrl_advance(sage_i64* ctrl_dev, sage_i64 d_counter, sage_i64 d_stamp, 
 /* sage_sample_fanout for callers that cannot allocate device memory (code under HIP-graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
  * reference.  Same arguments, outputs and results as sage_sample_fanout, without the workspace:
- * the counters, offsets, flags, ranks and scan state live in a file-scope device array of
+ * the hop counters, the tickets and the per-workgroup totals of its prefix exchanges live in a file-scope device array of
  * SAGE_STATIC_SCRATCH_BYTES inside the library (one copy per GPU, held until the process ends;
  * its address is resolved once per device on the first call made with that device current).
  * The call allocates and frees nothing.  node_cap / edge_cap whose
  * sage_sample_workspace_bytes() exceeds SAGE_STATIC_SCRATCH_BYTES are rejected with SAGE_ELIMIT
- * (the default covers batch 512 at fan-out 25/10 — node_cap 141,312, edge_cap 140,800, 2.4 MB —
- * with room to spare).  All calls on one GPU share that GPU's array: two calls that overlap on
+ * (batch 512 at fan-out 25/10 — node_cap 141,312, edge_cap 140,800 — needs 1.1 MB).  All calls on one GPU share that GPU's array: two calls that overlap on
  * one GPU (different streams or threads) race; serialise them or use sage_sample_fanout. */
 #define SAGE_STATIC_SCRATCH_BYTES (8u << 20)
 int sage_sample_fanout_static(const sage_i64* colptr, const sage_i64* row, sage_i64 num_nodes,
