@@ -1,0 +1,324 @@
+// Experiment (G): forward contraction C[M][N] = A[M][K] * B[N][K]^T in bf16x3 arithmetic from
+// fp32 operands, sized by what the L2 -> CU path delivers (≈10-12 TB/s chip-wide, measured with
+// scratch/x3p_fwd8.hip): 128 x 256 tiles (A and B rows are fetched once per 128 / 256 outputs),
+// 8 waves as 2 x 4 with 64 x 64 wave tiles (0.25 LDS fragment reads per MFMA), fp32 rows loaded
+// to registers one K-step ahead, split into hi / mid / lo planes on the way into a double-buffered
+// LDS image, one barrier per K-step, the contraction cut in SPLITK parts over blockIdx.y.
+// Build: hipcc -O3 --offload-arch=gfx950 scratch/x3_fwd_g.hip -o scratch/x3_fwd_g
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+#ifndef SPLITK
+#define SPLITK 2
+#endif
+#ifndef BMV
+#define BMV 128
+#endif
+constexpr int BM = BMV, BN = 256, NT = 512;
+constexpr int TI = BM / 32;            // 16-row blocks per wave tile (wave tile = BM/2 x 64)
+constexpr int ROWS = BM + BN;          // 384 rows per stage
+constexpr int PLANE = ROWS * 64;       // 24,576 B
+constexpr int STAGE = 3 * PLANE;       // 73,728 B
+constexpr int LPT = ROWS * 8 / NT;     // float4 loads per thread per K-step: 6
+
+__device__ inline unsigned cvt_pk(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline void split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = cvt_pk(x0, x1);
+  const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+  mid = cvt_pk(r0, r1);
+  const float q0 = r0 - __uint_as_float(mid << 16), q1 = r1 - __uint_as_float(mid & 0xffff0000u);
+  lo = cvt_pk(q0, q1);
+}
+
+template <int OFF>
+__device__ inline bf16x8 rd(unsigned addr) {
+  u32x4 v;
+#ifdef KO_READS
+  v = u32x4{addr, addr + OFF, 0x3f803f80u, 0x3f803f80u};
+  asm volatile("" : "+v"(v));
+  return __builtin_bit_cast(bf16x8, v);
+#endif
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <int OFF>
+__device__ inline void wr(unsigned addr, u32x2 v) {
+#ifdef KO_WRITES
+  asm volatile("" ::"v"(addr), "v"(v));
+  return;
+#endif
+  asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "i"(OFF) : "memory");
+}
+
+__global__ void __launch_bounds__(NT)
+x3_fwd_g(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr_ = wave >> 2, wc = wave & 3;
+  const int r16 = lane & 15, kg = lane >> 4;
+  const long m0 = (long)blockIdx.x * BM;
+  const int S = K / 32;
+  const int t_beg = (int)((long)S * blockIdx.y / gridDim.y), t_end = (int)((long)S * (blockIdx.y + 1) / gridDim.y);
+
+  // loader: float4 unit q = i * 512 + tid of the K-step's [384 rows][32 k] fp32 tile: row q / 8,
+  // k = 4 (q & 7); 8 threads cover one row's 128 bytes
+  const int rowl = threadIdx.x >> 3, c4 = threadIdx.x & 7;
+  const float* src[LPT];
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int row = i * 64 + rowl;
+    long grow = row < BM ? m0 + row : row - BM;
+    if (row < BM && grow >= M) grow = M - 1;
+    src[i] = (row < BM ? A : B) + grow * (long)K + c4 * 4;
+  }
+  floatx4 vv[2][LPT];     // register set p holds the K-step of parity p (relative to t_beg)
+  auto issue = [&](auto set_, int step) {
+    typedef const floatx4 __attribute__((address_space(1)))* GlobalVec;
+#ifdef KO_LOADS
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) vv[decltype(set_)::value][i] = *((GlobalVec)(src[i] + (long)step * 32));
+  };
+  const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
+  // the unit's 8 bytes per plane: row * 64 + ((slot ^ f(row)) * 16) + half * 8, slot = c4 >> 1
+  const unsigned w_off = lds0 + rowl * 64 + ((((c4 >> 1) ^ (-((rowl & 15) >> 2))) & 3) << 4) + (c4 & 1) * 8;
+  auto store_part = [&](auto stage_, auto lo_, auto hi_) {
+    constexpr int ST = decltype(stage_)::value, LO = decltype(lo_)::value, HI = decltype(hi_)::value;
+    const unsigned wb = w_off + ST * STAGE, wb2 = wb + 2 * PLANE;
+    floatx4 (&v)[LPT] = vv[ST];
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+#ifdef KO_SPLIT
+      h0 = __float_as_uint(v[i].x); h1 = __float_as_uint(v[i].y); m0_ = __float_as_uint(v[i].z); m1 = __float_as_uint(v[i].w); l0 = h0; l1 = h1;
+#else
+      split2(v[i].x, v[i].y, h0, m0_, l0);
+      split2(v[i].z, v[i].w, h1, m1, l1);
+#endif
+      if (i == 0) { wr<0 * 4096>(wb, u32x2{h0, h1}); wr<PLANE + 0 * 4096>(wb, u32x2{m0_, m1}); wr<0 * 4096>(wb2, u32x2{l0, l1}); }
+      if (i == 1) { wr<1 * 4096>(wb, u32x2{h0, h1}); wr<PLANE + 1 * 4096>(wb, u32x2{m0_, m1}); wr<1 * 4096>(wb2, u32x2{l0, l1}); }
+      if (i == 2) { wr<2 * 4096>(wb, u32x2{h0, h1}); wr<PLANE + 2 * 4096>(wb, u32x2{m0_, m1}); wr<2 * 4096>(wb2, u32x2{l0, l1}); }
+      if (i == 3) { wr<3 * 4096>(wb, u32x2{h0, h1}); wr<PLANE + 3 * 4096>(wb, u32x2{m0_, m1}); wr<3 * 4096>(wb2, u32x2{l0, l1}); }
+      if (i == 4) { wr<4 * 4096>(wb, u32x2{h0, h1}); wr<PLANE + 4 * 4096>(wb, u32x2{m0_, m1}); wr<4 * 4096>(wb2, u32x2{l0, l1}); }
+      if (LPT > 5 && i == 5) { wr<5 * 4096>(wb, u32x2{h0, h1}); wr<PLANE + 5 * 4096>(wb, u32x2{m0_, m1}); wr<5 * 4096>(wb2, u32x2{l0, l1}); }
+    }
+  };
+
+  floatx4 acc[TI][4];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+  const unsigned lane_off = r16 * 64 + (((kg ^ (-(r16 >> 2))) & 3) << 4);
+  const unsigned a_off = lds0 + lane_off + wr_ * (BM / 2) * 64;
+  const unsigned b_off = lds0 + lane_off + (BM + wc * 64) * 64;
+
+#ifdef KO_MFMA
+#define MF(ai, pa, bj, pb) asm volatile("" : "+v"(acc[ai][bj]) : "v"(a[ai][pa]), "v"(b[bj][pb]))
+#else
+#define MF(ai, pa, bj, pb) acc[ai][bj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai][pa], b[bj][pb], acc[ai][bj], 0, 0, 0)
+#endif
+#if BMV == 128
+#define PROD(pa, pb)                                                                                \
+  do {                                                                                              \
+    MF(0, pa, 0, pb); MF(1, pa, 0, pb); MF(2, pa, 0, pb); MF(3, pa, 0, pb);                         \
+    MF(0, pa, 1, pb); MF(1, pa, 1, pb); MF(2, pa, 1, pb); MF(3, pa, 1, pb);                         \
+    MF(0, pa, 2, pb); MF(1, pa, 2, pb); MF(2, pa, 2, pb); MF(3, pa, 2, pb);                         \
+    MF(0, pa, 3, pb); MF(1, pa, 3, pb); MF(2, pa, 3, pb); MF(3, pa, 3, pb);                         \
+  } while (0)
+#define RDA(p, base, off) RD4(a, p, base, off)
+#define AREGS(x, p) "+v"(x[0][p]), "+v"(x[1][p]), "+v"(x[2][p]), "+v"(x[3][p])
+#else
+#define PROD(pa, pb)                                                                                \
+  do {                                                                                              \
+    MF(0, pa, 0, pb); MF(1, pa, 0, pb); MF(0, pa, 1, pb); MF(1, pa, 1, pb);                         \
+    MF(0, pa, 2, pb); MF(1, pa, 2, pb); MF(0, pa, 3, pb); MF(1, pa, 3, pb);                         \
+  } while (0)
+#define RDA(p, base, off)                                                                           \
+  do {                                                                                              \
+    a[0][p] = rd<(off)>(base); a[1][p] = rd<(off) + 1024>(base);                                    \
+  } while (0)
+#define AREGS(x, p) "+v"(x[0][p]), "+v"(x[1][p])
+#endif
+#define RD4(arr, p, base, off)                                                                      \
+  do {                                                                                              \
+    arr[0][p] = rd<(off)>(base); arr[1][p] = rd<(off) + 1024>(base);                                \
+    arr[2][p] = rd<(off) + 2048>(base); arr[3][p] = rd<(off) + 3072>(base);                         \
+  } while (0)
+#define WAIT4(n, x, p, y, q)                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")"                                                          \
+               : AREGS(x, p), "+v"(y[0][q]), "+v"(y[1][q]), "+v"(y[2][q]), "+v"(y[3][q]))
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I3 = std::integral_constant<int, 3>;
+  using I6 = std::integral_constant<int, LPT>;
+
+  // step t: LDS stage ST holds step t; register set ST^1 holds step t+1 (loaded during step
+  // t-1), set ST takes step t+2.  The two waves of a SIMD (w and w+4) run the step's two halves
+  // in opposite order, so one splits / stores while the other multiplies.
+  auto step = [&](auto stage_, int t) {
+    constexpr int ST = decltype(stage_)::value;
+    using NX = std::integral_constant<int, ST ^ 1>;
+    const unsigned ab = a_off + ST * STAGE, bb = b_off + ST * STAGE;
+    bf16x8 a[TI][3], b[4][3];
+    auto products = [&]() {
+      RDA(2, ab, 2 * PLANE);
+      RD4(b, 0, bb, 0);
+      RDA(0, ab, 0);
+      RD4(b, 2, bb, 2 * PLANE);
+      __builtin_amdgcn_sched_barrier(0);
+#if BMV == 128
+      WAIT4(8, a, 2, b, 0);
+#else
+      WAIT4(6, a, 2, b, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      PROD(2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      RDA(1, ab, PLANE);
+      RD4(b, 1, bb, PLANE);
+#if BMV == 128
+      WAIT4(8, a, 0, b, 2);
+#else
+      WAIT4(6, a, 0, b, 2);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      PROD(0, 2);
+      PROD(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WAIT4(0, a, 1, b, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      PROD(1, 1);
+      PROD(1, 0);
+      PROD(0, 1);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    issue(stage_, t + 2 < t_end ? t + 2 : t_end - 1);   // unconditional (clamped): the compiler's vmcnt counts stay exact
+    __builtin_amdgcn_sched_barrier(0);
+#ifndef NO_STAGGER
+    if (wave < 4) {
+#endif
+      store_part(NX{}, I0{}, I6{});
+      __builtin_amdgcn_sched_barrier(0);
+      products();
+#ifndef NO_STAGGER
+    } else {
+      products();
+      store_part(NX{}, I0{}, I6{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#endif
+    __builtin_amdgcn_s_barrier();
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  if (t_beg < t_end) {
+    issue(S0{}, t_beg);
+    issue(S1{}, t_beg + 1 < t_end ? t_beg + 1 : t_beg);
+    store_part(S0{}, I0{}, I6{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int t = t_beg;
+    for (; t + 1 < t_end; t += 2) {
+      step(S0{}, t);
+      step(S1{}, t + 1);
+    }
+    if (t < t_end) step(S0{}, t);
+  }
+
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long col = wc * 64 + j * 16 + r16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const long row = m0 + wr_ * (BM / 2) + i * 16 + kg * 4 + e;
+        if (row < M) {
+          if (gridDim.y > 1) atomicAdd(C + row * N + col, acc[i][j][e]);
+          else C[row * N + col] = acc[i][j][e];
+        }
+      }
+    }
+}
+
+#define CK(x)                                                                  \
+  do {                                                                         \
+    hipError_t e_ = (x);                                                       \
+    if (e_ != hipSuccess) {                                                    \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return 1;                                                                \
+    }                                                                          \
+  } while (0)
+
+int main() {
+  const int M = getenv("MROWS") ? atoi(getenv("MROWS")) : 13100, N = 256, K = 1216;
+  std::vector<float> a((size_t)M * K), b((size_t)N * K);
+  srand(1);
+  for (auto& v : a) v = (rand() % 200001 - 100000) / 100000.f * ((rand() & 7) == 0 ? 37.f : 1.f);
+  for (auto& v : b) v = (rand() % 200001 - 100000) / 1000000.f;
+  float *da, *db, *dc;
+  CK(hipMalloc(&da, a.size() * 4));
+  CK(hipMalloc(&db, b.size() * 4));
+  CK(hipMalloc(&dc, (size_t)M * N * 4));
+  CK(hipMemcpy(da, a.data(), a.size() * 4, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, b.data(), b.size() * 4, hipMemcpyHostToDevice));
+  const int lds_bytes = 2 * STAGE;
+  CK(hipFuncSetAttribute((const void*)x3_fwd_g, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  dim3 grid((M + BM - 1) / BM, SPLITK);
+  CK(hipMemset(dc, 0, (size_t)M * N * 4));
+  x3_fwd_g<<<grid, NT, lds_bytes>>>(da, db, dc, M, N, K);
+  CK(hipDeviceSynchronize());
+  std::vector<float> c((size_t)M * N);
+  CK(hipMemcpy(c.data(), dc, c.size() * 4, hipMemcpyDeviceToHost));
+  double err_k = 0, err_f = 0;
+  for (int s = 0; s < 4000; ++s) {
+    const int r = s < 64 ? M - 1 - s : rand() % M, col = rand() % N;
+    double ref = 0, mag = 0;
+    float f32 = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const double p = (double)a[(size_t)r * K + k] * b[(size_t)col * K + k];
+      ref += p;
+      mag += fabs(p);
+      f32 = fmaf(a[(size_t)r * K + k], b[(size_t)col * K + k], f32);
+    }
+    err_k = fmax(err_k, fabs(ref - c[(size_t)r * N + col]) / mag);
+    err_f = fmax(err_f, fabs(ref - f32) / mag);
+  }
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 20;
+  for (int i = 0; i < 3; ++i) x3_fwd_g<<<grid, NT, lds_bytes>>>(da, db, dc, M, N, K);
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) x3_fwd_g<<<grid, NT, lds_bytes>>>(da, db, dc, M, N, K);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double us = ms * 1e3 / reps;
+  printf("max err / sum|a*b|: x3_fwd_g %.3g, sequential fp32 fma %.3g (2^-24 = %.3g)\n", err_k, err_f, ldexp(1.0, -24));
+  printf("M %d: %d x %d workgroups, tile %d x %d: %.1f us   %.1f fp32-equivalent TF/s\n", M, grid.x, grid.y, BM, BN, us,
+         2.0 * M * N * K / us * 1e-6);
+  return err_k < 1e-5 ? 0 : 2;
+}
