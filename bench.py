@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="headline from the serial schedule (every kernel of a step on one stream) instead of "
                          "the overlapped one (layer-0 gather of batch s+1 on the side stream beside batch s)")
+    ap.add_argument("--module-path", action="store_true",
+                    help="max_pool / mean_pool through the module path (autograd Functions) instead of the engine")
     ap.add_argument("--probe-steps", type=int, default=300,
                     help="timed steps of the serial roofline probe run (gather kernel alone on its stream)")
     ap.add_argument("--lstm-num-inputs", type=int, default=25, help="--aggregator lstm: LSTM_NUM_INPUTS")
@@ -163,20 +165,9 @@ def trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, worl
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense peaks
 
 
-def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_mode):
-    """Aggregators the static-shape engine does not run (lstm; the pooling ones with
-    --module-path): fig2a's step through the module path (autograd Functions over the same
-    kernels).  `roofline` is for the dominant kernels here, the large MFMA contractions: every
-    sage_linear_concat_fwd / sage_linear_dweight(2) call above 1 GFLOP is bracketed by a HIP
-    event pair on its stream; achieved = sum of their flops / sum of their event times."""
-    import torch.nn.functional as F
-
-    from graphsage_amd import ops
-    from graphsage_amd.samplers import UniformLoader
-    gen = torch.Generator().manual_seed(0)
-    train = torch.randperm(N, generator=gen)[:n_train]
-    loader = UniformLoader(data, num_neighbors=K, input_nodes=train, batch_size=B, shuffle=False, seed=0)
-    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+def bracket_contractions(ops):
+    """Wrap the contraction entry points of graphsage_amd.ops: while rec["on"], every call above
+    1 GFLOP is bracketed by a HIP event pair on its stream.  Returns rec (flops, event pairs)."""
     rec = {"on": False, "flops": 0.0, "pairs": []}
 
     def bracket(name, flops_of):
@@ -195,14 +186,55 @@ def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_
             return out
         setattr(ops, name, wrapped)
 
-    def fwd_flops(a1, w1, a2=None, w2=None, m=None, rows1=None, **kw):
-        mm = m if m is not None else (rows1.numel() if rows1 is not None else a1.size(0))
+    def rows_of(m, m_dev, default):
+        mm = m if m is not None else default
+        # a device-side count bounds the rows that are really contracted (reading it synchronises:
+        # measurement runs only)
+        return min(mm, int(m_dev)) if m_dev is not None else mm
+
+    def fwd_flops(a1, w1, a2=None, w2=None, m=None, m_dev=None, rows1=None, **kw):
+        mm = rows_of(m, m_dev, rows1.numel() if rows1 is not None else a1.size(0))
         return 2.0 * mm * w1.size(0) * (w1.size(1) + (w2.size(1) if w2 is not None else 0))
     bracket("linear_concat_fwd", fwd_flops)
-    bracket("linear_dweight", lambda dout, a, m=None, **kw: 2.0 * (m if m is not None else dout.size(0)) * dout.size(1) * a.size(1))
-    bracket("linear_dweight2", lambda dout, a1, dw1, a2, dw2, m=None, **kw:
-            2.0 * (m if m is not None else dout.size(0)) * dout.size(1) * (a1.size(1) + a2.size(1)))
-    bracket("linear_dinput", lambda dout, w, m=None, **kw: 2.0 * (m if m is not None else dout.size(0)) * w.size(0) * w.size(1))
+    bracket("linear_dweight", lambda dout, a, m=None, m_dev=None, **kw:
+            2.0 * rows_of(m, m_dev, dout.size(0)) * dout.size(1) * a.size(1))
+    bracket("linear_dweight2", lambda dout, a1, dw1, a2, dw2, m=None, m_dev=None, **kw:
+            2.0 * rows_of(m, m_dev, dout.size(0)) * dout.size(1) * (a1.size(1) + a2.size(1)))
+    bracket("linear_dinput", lambda dout, w, m=None, m_dev=None, **kw:
+            2.0 * rows_of(m, m_dev, dout.size(0)) * w.size(0) * w.size(1))
+    bracket("linear_dinput2", lambda dout, w1, out1, w2, out2, m=None, m_dev=None, **kw:
+            2.0 * rows_of(m, m_dev, dout.size(0)) * w1.size(0) * (w1.size(1) + w2.size(1)))
+    return rec
+
+
+def mfma_roofline(rec, steps, gemm_mode):
+    t_ms = sum(a.elapsed_time(b) for a, b in rec["pairs"])
+    tf = rec["flops"] / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+    # bf16x3: six bf16 MFMA products per fp32 product, so the fp32-equivalent peak is bf16 / 6
+    peak = MFMA_PEAK_TFLOPS["bf16"] / 6.0 if gemm_mode == "bf16x3" else MFMA_PEAK_TFLOPS["f32"]
+    return {"bound": "mfma", "kernel": "MFMA contractions above 1 GFLOP (gemm_x3_kernel / gemm_x3_dw_kernel / gemm_kernel)",
+            "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+            "traffic": None, "flops_per_step": rec["flops"] / steps,
+            "gemm_ms_per_step": round(t_ms / steps, 4), "launches_per_step": len(rec["pairs"]) / steps,
+            "timing": "HIP events recorded around each call on its stream (fp32-equivalent flops; "
+                      "peak = bf16 dense peak / 6 products in bf16x3 mode)"}
+
+
+def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_mode):
+    """Aggregators the static-shape engine does not run (lstm; the pooling ones with
+    --module-path): fig2a's step through the module path (autograd Functions over the same
+    kernels).  `roofline` is for the dominant kernels here, the large MFMA contractions: every
+    sage_linear_concat_fwd / sage_linear_dweight(2) call above 1 GFLOP is bracketed by a HIP
+    event pair on its stream; achieved = sum of their flops / sum of their event times."""
+    import torch.nn.functional as F
+
+    from graphsage_amd import ops
+    from graphsage_amd.samplers import UniformLoader
+    gen = torch.Generator().manual_seed(0)
+    train = torch.randperm(N, generator=gen)[:n_train]
+    loader = UniformLoader(data, num_neighbors=K, input_nodes=train, batch_size=B, shuffle=False, seed=0)
+    opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    rec = bracket_contractions(ops)
 
     def step(batch):
         opt.zero_grad()
@@ -222,10 +254,6 @@ def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_
         loss = step(next(it))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    gemm_ms = sum(a.elapsed_time(b) for a, b in rec["pairs"])
-    tf = rec["flops"] / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-    # bf16x3: six bf16 MFMA products per fp32 product, so the fp32-equivalent peak is bf16 / 6
-    peak = MFMA_PEAK_TFLOPS["bf16"] / 6.0 if gemm_mode == "bf16x3" else MFMA_PEAK_TFLOPS["f32"]
     extra = f", LSTM_NUM_INPUTS {args.lstm_num_inputs}" if args.aggregator == "lstm" else ""
     print(json.dumps({
         "metric": "Reddit GraphSAGE-mean 25/10 fwd+bwd seed nodes/s; gather GB/s vs HBM peak",
@@ -236,12 +264,7 @@ def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_
                                f"hidden {args.hidden}, aggregator {args.aggregator}{extra}, Adam lr {args.lr}, fig2a step "
                                "(supervised term only), module path",
                    "parallelism": "dp1", "global_batch": B},
-        "roofline": {"bound": "mfma", "kernel": "MFMA contractions above 1 GFLOP (gemm_x3_kernel / gemm_x3_dw_kernel / gemm_kernel)",
-                     "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                     "traffic": None, "flops_per_step": rec["flops"] / args.steps,
-                     "gemm_ms_per_step": round(gemm_ms / args.steps, 4), "launches_per_step": len(rec["pairs"]) / args.steps,
-                     "timing": "HIP events recorded around each call on its stream (fp32-equivalent flops; "
-                               "peak = bf16 dense peak / 6 products in bf16x3 mode)"},
+        "roofline": mfma_roofline(rec, args.steps, gemm_mode),
         "cpu_baseline": None, "gemm_mode": gemm_mode, "final_loss": round(float(loss.detach()), 5),
         "variant": "module-path"}), flush=True)
 
@@ -301,7 +324,9 @@ def main():
     if args.aggregator == "lstm":
         settings.LSTM_NUM_INPUTS = args.lstm_num_inputs
     model = GraphSAGE(Fdim, args.hidden, args.aggregator, len(K), C).to(dev)
-    on_engine = args.aggregator in _REDUCE and args.variant != "trainer-module"
+    pooling = args.aggregator in ("max_pool", "mean_pool")
+    on_engine = (args.aggregator in _REDUCE and args.variant != "trainer-module"
+                 and not (pooling and (args.module_path or args.variant != "fig2a")))
     if not on_engine and args.variant == "fig2a":
         if world != 1:
             raise SystemExit("module-path aggregators are single-GPU measurements here")
@@ -331,7 +356,9 @@ def main():
         return step * world + rank
 
     use_graph = args.graph and not args.no_graph
-    probe = not args.no_probe
+    # the hbm roofline probe times the layer-0 gather; with a pooling aggregator the dominant
+    # kernels are the contractions (MFMA roofline below) and the gather reads pool outputs
+    probe = not args.no_probe and not pooling
     attached = probe and not args.bracket_probe
 
     def make_engine(mdl, overlap):
@@ -416,7 +443,7 @@ def main():
         return 4.0 * Fdim * e_b + 4.0 * Fdim * t1 + 8.0 * (2 * e_b + t1 + launches)
 
     base = max(args.settle_steps, 0)
-    overlapped = not args.serial and not use_graph
+    overlapped = not args.serial and not use_graph and not pooling
     import copy
     # 1. the roofline probe: serial schedule (every kernel of a step on ONE stream), where the
     #    HBM-bound layer-0 gather has the chip to itself and its event-timed duration is its own
@@ -439,6 +466,25 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         roofline = None
+        if pooling and world == 1 and not args.no_probe:
+            # MFMA roofline of the contractions: a short run of the same steps with every call
+            # going through the wrappers of ops.py (no call tapes), each contraction above
+            # 1 GFLOP bracketed by a HIP event pair
+            rec = bracket_contractions(ops)
+            pe = make_engine(copy.deepcopy(model), False)
+            pe.use_tapes = False
+            n_probe = max(1, min(20, args.steps))
+            for s_ in range(3):
+                pe.step(seeds_of(s_), counter_of(s_))
+            torch.cuda.synchronize()
+            rec["on"] = True
+            for s_ in range(3, 3 + n_probe):
+                pe.step(seeds_of(s_), counter_of(s_))
+            torch.cuda.synchronize()
+            rec["on"] = False
+            roofline = mfma_roofline(rec, n_probe, gemm_mode)
+            roofline["schedule"] = f"separate run of {n_probe} steps without call tapes"
+            del pe
         if probe:
             src = probe_res if probe_res is not None else res
             n_launch = src["gather_ms"].numel()

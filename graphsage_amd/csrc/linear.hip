@@ -37,6 +37,16 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int kThreads = 256;
 constexpr int BK = 32;
 
+// Split-K over blockIdx.z with a DEVICE-side contraction length: the host sized the grid for the
+// capacity (its k_chunk), the actual count can be much smaller (the pooling aggregators contract
+// over all sampled nodes: capacity 141k rows, ~81k sampled) — deal the actual length evenly over
+// the gridDim.z slices instead of leaving the upper ones empty.
+__device__ inline int split_chunk(int host_chunk, bool device_count, int k_lim) {
+  if (!device_count) return host_chunk;
+  const int per = (k_lim + static_cast<int>(gridDim.z) - 1) / static_cast<int>(gridDim.z);
+  return (per + BK - 1) / BK * BK;
+}
+
 struct Operand {
   const float* p;          // base pointer
   int64_t ld;              // row stride in floats
@@ -678,8 +688,9 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
     }
     int k_beg = 0, k_end = k_lim;
     if (g.k_chunk > 0) {
-      k_beg = bz * g.k_chunk;
-      k_end = k_beg + g.k_chunk < k_lim ? k_beg + g.k_chunk : k_lim;
+      const int chunk = split_chunk(g.k_chunk, g.k_dev != nullptr, k_lim);
+      k_beg = bz * chunk;
+      k_end = k_beg + chunk < k_lim ? k_beg + chunk : k_lim;
     }
     if (k_beg >= k_end) continue;
 
@@ -1049,8 +1060,9 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   }
   int k_beg = 0, k_end = k_lim;
   if (g.k_chunk > 0) {
-    k_beg = blockIdx.z * g.k_chunk;
-    k_end = k_beg + g.k_chunk < k_lim ? k_beg + g.k_chunk : k_lim;
+    const int chunk = split_chunk(g.k_chunk, g.k_dev != nullptr, k_lim);
+    k_beg = blockIdx.z * chunk;
+    k_end = k_beg + chunk < k_lim ? k_beg + chunk : k_lim;
   }
   if (m0 >= m_lim || k_beg >= k_end) return;   // block-uniform: EXEC stays full for the transposing reads
 

@@ -355,6 +355,34 @@ __global__ void adam_kernel(float* __restrict__ param, const float* grad,
 
 __global__ void bump_step2_kernel(const int64_t* step_in, int64_t* step_out) { *step_out = *step_in + 1; }
 
+
+// relu backward of the pool Linear (threshold_backward): dz = out > 0 ? dout : 0, one 16-byte
+// vector (or one float) per thread; the consumed dout rows are handed back zeroed on request
+template <bool V4>
+__global__ void __launch_bounds__(kBlock)
+relu_bwd_kernel(float* __restrict__ dout, int64_t ld_dout, const float* __restrict__ out, int64_t ld_out,
+                int64_t m, const int64_t* __restrict__ m_dev, int n, float* __restrict__ dz, int64_t ld_dz,
+                int clear_dout) {
+  const int64_t rows = dev_count(m_dev, m);
+  const int per_row = V4 ? n / 4 : n;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t r = i / per_row;
+  if (r >= rows) return;
+  const int c = static_cast<int>(i - r * per_row) * (V4 ? 4 : 1);
+  if (V4) {
+    float4* gp = reinterpret_cast<float4*>(dout + r * ld_dout + c);
+    const float4 g = *gp;
+    const float4 o = *reinterpret_cast<const float4*>(out + r * ld_out + c);
+    *reinterpret_cast<float4*>(dz + r * ld_dz + c) =
+        make_float4(o.x > 0.f ? g.x : 0.f, o.y > 0.f ? g.y : 0.f, o.z > 0.f ? g.z : 0.f, o.w > 0.f ? g.w : 0.f);
+    if (clear_dout) *gp = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    const float g = dout[r * ld_dout + c];
+    dz[r * ld_dz + c] = out[r * ld_out + c] > 0.f ? g : 0.f;
+    if (clear_dout) dout[r * ld_dout + c] = 0.f;
+  }
+}
+
 }  // namespace
 }  // namespace sage
 
@@ -403,6 +431,27 @@ extern "C" int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, s
         dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
   }
   SAGE_CHECK_LAUNCH("l2norm_relu_bwd_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_relu_bwd(float* dout, sage_i64 ld_dout, const float* out, sage_i64 ld_out, sage_i64 m,
+                             const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz, int clear_dout,
+                             void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && ld_dout >= n && ld_out >= n && ld_dz >= n, SAGE_EINVAL, "sage_relu_bwd: bad shape");
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(dout && out && dz, SAGE_EINVAL, "sage_relu_bwd: NULL pointer argument");
+  SAGE_REQUIRE(!clear_dout || dz != dout, SAGE_EINVAL, "sage_relu_bwd: clear_dout excludes dz aliasing dout");
+  const bool v4 = n % 4 == 0 && ld_dout % 4 == 0 && ld_out % 4 == 0 && ld_dz % 4 == 0 && vec16(dout) && vec16(out) &&
+                  vec16(dz);
+  const int64_t per_row = v4 ? n / 4 : n;
+  const unsigned grid = static_cast<unsigned>(cdiv(m * per_row, kBlock));
+  if (v4) {
+    relu_bwd_kernel<true><<<grid, kBlock, 0, stream>>>(dout, ld_dout, out, ld_out, m, m_dev, n, dz, ld_dz, clear_dout);
+  } else {
+    relu_bwd_kernel<false><<<grid, kBlock, 0, stream>>>(dout, ld_dout, out, ld_out, m, m_dev, n, dz, ld_dz, clear_dout);
+  }
+  SAGE_CHECK_LAUNCH("relu_bwd_kernel");
   return SAGE_OK;
 }
 

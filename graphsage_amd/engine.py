@@ -19,7 +19,8 @@ import torch
 from . import _lib, ops
 from .dist import PendingReduce, all_reduce_flat
 
-_REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max', 'gcn': 'gcn'}   # gcn: no root weight (lin_r)
+# gcn: no root weight (lin_r); the pooling aggregators reduce relu(pool(x_j)) instead of x_j
+_REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max', 'gcn': 'gcn', 'max_pool': 'max', 'mean_pool': 'mean'}
 
 
 def flatten_parameters(model, pad_to=16):
@@ -33,7 +34,10 @@ def flatten_parameters(model, pad_to=16):
     def ld_of(p):
         return (p.size(1) + pad_to - 1) // pad_to * pad_to if p.dim() == 2 else None
 
-    total = sum(p.size(0) * ld_of(p) if p.dim() == 2 else p.numel() for p in params)
+    def vec_len(p):      # vectors (the pool bias) padded as well: what follows stays 64-byte aligned
+        return (p.numel() + pad_to - 1) // pad_to * pad_to
+
+    total = sum(p.size(0) * ld_of(p) if p.dim() == 2 else vec_len(p) for p in params)
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     layout = []
     off = 0
@@ -43,8 +47,8 @@ def flatten_parameters(model, pad_to=16):
             n = p.size(0) * ld
             view = flat[off:off + n].view(p.size(0), ld)[:, :p.size(1)]
         else:
-            n = p.numel()
-            view = flat[off:off + n].view(p.shape)
+            n = vec_len(p)
+            view = flat[off:off + p.numel()].view(p.shape)
         view.copy_(p.data)
         p.data = view
         layout.append((off, n, tuple(p.shape), ld_of(p)))
@@ -58,7 +62,10 @@ def views_like(flat, layout):
         if ld is not None:
             out.append(flat[off:off + n].view(shape[0], ld)[:, :shape[1]])
         else:
-            out.append(flat[off:off + n].view(shape))
+            numel = 1
+            for d in shape:
+                numel *= d
+            out.append(flat[off:off + numel].view(shape))
     return out
 
 
@@ -81,6 +88,15 @@ class SageTrainEngine:
         self.model = model
         self.reduce = _REDUCE[model.aggregator]
         self.root = model.aggregator != 'gcn'      # gcn layers have no lin_r (reference layers/sage.py:62-65)
+        # max_pool / mean_pool (reference layers/sage.py:75-76, :201-207): relu(pool(x_j)) is
+        # row-wise, so the pool Linear runs once per SOURCE NODE of the layer (its own static
+        # buffer P), the segments then reduce rows of P; backward: scatter through the reduce
+        # into dP, relu mask, pool weight / bias gradients, and (above layer 0) the input gradient
+        self.pool = model.aggregator in ('max_pool', 'mean_pool')
+        if self.pool and unsup:
+            raise NotImplementedError("engine: the pooling aggregators run the supervised (fig2a) step only")
+        if self.pool:
+            overlap_gather = False    # the layer-0 gather reads P, which needs this step's weights
         self.features, self.labels = features, labels
         self.B = int(batch_size)
         self.L = len(model.layers)
@@ -164,10 +180,18 @@ class SageTrainEngine:
                     a['dh'] = padded(t_cap, fout)
                 else:
                     a['dy'] = padded(t_cap, fout)     # unsup: gradient w.r.t. the normalised logits
-                if i > 0:
+                if i > 0 or self.pool:
                     a['dagg'] = padded(t_cap, fin)
                     if self.reduce == 'max':   # the backward routes to the edge that attained the max
                         a['argmax'] = torch.zeros((t_cap, fin), dtype=torch.int64, device=dev)
+                if self.pool:
+                    # sources of layer i = the nodes after hop L-i (all sampled nodes for layer 0)
+                    a['src_hop'] = self.L - i
+                    s_cap = self.hop_cap[self.L - i]
+                    a['s_cap'] = s_cap
+                    a['P'] = padded(s_cap, fin)       # relu(pool(x)) per source row
+                    a['dP'] = padded(s_cap, fin)      # gradient w.r.t. P (zero between steps)
+                    a['dpre'] = padded(s_cap, fin)    # gradient w.r.t. pool(x): dP * [P > 0]
                 act.append(a)
             return act
         self.acts = [make_act() for _ in range(nvar)]
@@ -193,6 +217,7 @@ class SageTrainEngine:
         self.counter = 0
         self.graphs = None
         self._tapes = {}        # recorded C-ABI call sequences, keyed by (what, slot, ..., stream)
+        self.use_tapes = True   # False: every call goes through the validating wrappers of ops.py (measurement hooks)
         self._pending = PendingReduce()   # data parallel: the gradient all-reduce not yet applied
         # data parallel: the host may run at most `run_ahead` steps (= un-waited collectives)
         # ahead of the device: it blocks on the event recorded that many steps ago
@@ -317,6 +342,13 @@ class SageTrainEngine:
         recorded C-ABI calls afterwards: every pointer the engine passes is static.  `stream`
         (default: the current one) is where the calls go; a replay needs no stream switch."""
         cur = torch.cuda.current_stream()
+        if not self.use_tapes:
+            if stream is not None and stream != cur:
+                with torch.cuda.stream(stream):
+                    fn()
+            else:
+                fn()
+            return
         key = (what, slot, (stream or cur).cuda_stream)
         tape = self._tapes.get(key)
         if tape is None:
@@ -337,6 +369,9 @@ class SageTrainEngine:
         if events is None:
             self._taped('gather0', slot, lambda: self._gather_layer0(slot), stream)
             return
+        if self.pool:
+            raise NotImplementedError("gather_layer0(events=...): with a pooling aggregator the step's first "
+                                      "kernel is the pool contraction, not the gather")
         cur = torch.cuda.current_stream()
         key = ('gather0t', slot, (stream or cur).cuda_stream)
         entry = self._tapes.get(key)
@@ -356,9 +391,21 @@ class SageTrainEngine:
 
     def _gather_layer0(self, slot, events=None):
         a, buf = self.act[0], self.bufs[slot]
+        if self.pool:
+            self._pool_forward(slot, 0, self.features, buf.node)
+            ops.gather_reduce_fwd(a['P'], buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
+                                  num_targets_dev=self.n_dev[slot][a['hop']], out=self.agg0[slot],
+                                  want_argmax=self.reduce == 'max', argmax=a.get('argmax'), events=events)
+            return
         ops.gather_reduce_fwd(self.features, buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
                               node_map=buf.node, num_targets_dev=self.n_dev[slot][a['hop']],
                               out=self.agg0[slot], want_argmax=False, events=events)
+
+    def _pool_forward(self, slot, i, x, node_map):
+        """P = relu(x[rows] @ pool.weight^T + pool.bias) over the layer's source rows."""
+        a, layer = self.act[i], self.model.layers[i]
+        ops.linear_concat_fwd(x, layer.pool.weight, bias=layer.pool.bias, relu=True, m=a['s_cap'],
+                              m_dev=self.n_dev[slot][a['src_hop']], rows1=node_map, out=a['P'])
 
     def forward_backward(self, slot=0, skip_gather0=False):
         self.last_slot = slot
@@ -404,9 +451,11 @@ class SageTrainEngine:
                 elif not skip_gather0:
                     self._gather_layer0(slot)
             else:
-                lib.gather_reduce_fwd(x, buf.seg_ptr, buf.src, t_cap, self.reduce, node_map=None,
-                                      num_targets_dev=t_dev, out=agg, want_argmax=self.reduce == 'max',
-                                      argmax=a.get('argmax'))
+                if self.pool:
+                    self._pool_forward(slot, i, x, None)
+                lib.gather_reduce_fwd(a['P'] if self.pool else x, buf.seg_ptr, buf.src, t_cap, self.reduce,
+                                      node_map=None, num_targets_dev=t_dev, out=agg,
+                                      want_argmax=self.reduce == 'max', argmax=a.get('argmax'))
             # The GEMMs ADD into z (stream-K / split-K partial sums), and every z starts as zeros:
             # the consumer hands it back zeroed (clear_z of the normalise kernel, of the fused
             # loss kernel in the supervised step), so there is no fill kernel.  Only the unsup
@@ -476,7 +525,9 @@ class SageTrainEngine:
                                     self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
             else:
                 lib.linear_dweight(a['dz'], agg_i, m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
-            if i > 0:
+            if self.pool:
+                self._pool_backward(slot, i, x_in, rows)
+            elif i > 0:
                 prev = act[i - 1]
                 if self.root:
                     lib.linear_dinput2(a['dz'], layer.lin_r.weight, prev['dh'], layer.lin_l.weight, a['dagg'],
@@ -485,6 +536,26 @@ class SageTrainEngine:
                     lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       argmax=a.get('argmax'), num_targets_dev=t_dev)
+
+    def _pool_backward(self, slot, i, x_in, rows):
+        """Layer i's aggregate path with a pooling aggregator: d agg -> (through the reduce) d P ->
+        (relu) d pool(x) -> pool weight / bias gradients and, above layer 0, the input gradient."""
+        a, layer, buf, lib = self.act[i], self.model.layers[i], self.bufs[slot], ops
+        t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
+        s_cap, s_dev = a['s_cap'], self.n_dev[slot][a['src_hop']]
+        if i > 0:      # root term into the previous layer's dh (overwrites its first t rows), d agg beside it
+            lib.linear_dinput2(a['dz'], layer.lin_r.weight, self.act[i - 1]['dh'], layer.lin_l.weight, a['dagg'],
+                               m=t_cap, m_dev=t_dev)
+        else:
+            lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
+        lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, a['dP'],
+                              argmax=a.get('argmax'), num_targets_dev=t_dev)
+        lib.relu_bwd(a['dP'], a['P'], m=s_cap, m_dev=s_dev, dz=a['dpre'], clear_dout=True)
+        lib.linear_dweight(a['dpre'], x_in, m=s_cap, m_dev=s_dev, rows=rows, dw=self.gviews[layer.pool.weight],
+                           dbias=self.gviews[layer.pool.bias])
+        if i > 0:
+            lib.linear_dinput(a['dpre'], layer.pool.weight, m=s_cap, m_dev=s_dev, out=self.act[i - 1]['dh'],
+                              accumulate=True)
 
     def make_pos_neg(self, slot, counter):
         """unsup: positive = one uniform in-neighbour of every batch node in the full graph,

@@ -590,6 +590,27 @@ def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None, 
     return y, (h if relu else None), inv_norm
 
 
+def relu_bwd(dout, out, m=None, m_dev=None, dz=None, clear_dout=False):
+    """dz = dout * [out > 0] (threshold_backward of relu(pool(x)), reference layers/sage.py:202,206).
+    clear_dout=True zeroes the consumed rows of dout."""
+    lib = _lib.load()
+    gp, ld_g = _mat(dout, "dout")
+    op, ld_o = _mat(out, "out")
+    m = dout.size(0) if m is None else int(m)
+    n = dout.size(1)
+    if out.size(1) != n or out.size(0) < m or dout.size(0) < m:
+        raise RuntimeError("relu_bwd: shape mismatch")
+    if dz is None:
+        dz = empty_rows(m, n, dout.device)
+    zp, ld_z = _mat(dz, "dz")
+    if dz.size(0) < m or dz.size(1) != n:
+        raise RuntimeError("relu_bwd: bad output buffer")
+    rc = lib.sage_relu_bwd(gp, ld_g, op, ld_o, m, _count(m_dev, "m_dev"), n, zp, ld_z, 1 if clear_dout else 0,
+                           _stream())
+    _lib.check(rc, "sage_relu_bwd")
+    return dz
+
+
 def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None, clear_dh=False):
     """Backward of relu(normalize(z)).  clear_dh=True zeroes the consumed rows of dh."""
     lib = _lib.load()

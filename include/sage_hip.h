@@ -349,6 +349,15 @@ int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_
                          int clear_dh /* 1: dh rows are zeroed after use (consume-and-clear) */,
                          void* stream);
 
+/* Gradient through the ReLU of the pool Linear, relu(pool(x_j)) at layers/sage.py:202,206 — what
+ * autograd's threshold_backward computes:  dz[r, :] = out[r, :] > 0 ? dout[r, :] : 0  for r < m
+ * (m_dev: optional device-side row count).  clear_dout != 0 also zeroes the consumed rows of
+ * dout (consume-and-clear: dout is the buffer the next step's scatter-add accumulates into);
+ * it excludes dz == dout.  Without it dz may alias dout. */
+int sage_relu_bwd(float* dout, sage_i64 ld_dout, const float* out, sage_i64 ld_out, sage_i64 m,
+                  const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz, int clear_dout,
+                  void* stream);
+
 /* Mean softmax cross-entropy over m rows and its gradient (F.cross_entropy of
  * experiments/fig2a/runners/graphsage_runners.py:43 / nn.CrossEntropyLoss of
  * trainers/node_level_graphsage_trainers.py:41).  labels are gathered through

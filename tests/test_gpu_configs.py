@@ -191,6 +191,55 @@ def test_reddit_shape_pool_step_matches_plain_torch(reddit, dev, aggregator):
             assert int(off.sum()) <= 0.01 * off.numel(), (name, int(off.sum()))
 
 
+@pytest.mark.parametrize("aggregator", ["max_pool", "mean_pool"])
+def test_reddit_shape_pool_engine_step_matches_module_path(reddit, dev, aggregator):
+    """The same step on the static-shape engine (pool Linear over all sampled nodes into a static
+    buffer, gather over its rows, scatter -> relu mask -> pool weight / bias gradients with the
+    contraction length read on the device) against the module path checked above: loss, every
+    gradient, the parameters after Adam."""
+    import copy
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    data, graph = reddit
+    torch.manual_seed(1)
+    model = GraphSAGE(602, 256, aggregator, 2, 41).to(dev)
+    ref_model = copy.deepcopy(model)
+    engine = SageTrainEngine(model, NeighborSampler.from_graph(graph, [25, 10], seed=0), graph.features(data),
+                             graph.labels(data), B, lr=1e-3, keep_grads=True)
+    seeds = torch.randperm(data.num_nodes, generator=torch.Generator().manual_seed(2))[:B].to(dev)
+    loss = engine.step(seeds, counter=11)
+    st = engine.buf.state.tolist()
+    nn_, ne = st[0], st[1]
+    node, ei = engine.buf.node[:nn_], torch.stack([engine.buf.src[:ne], engine.buf.dst[:ne]])
+    ref_model.prune_to_seeds = True
+    opt = torch.optim.Adam(ref_model.parameters(), lr=1e-3)
+    ref_loss = F.cross_entropy(ref_model(data.x[node], ei)[:B], data.y[seeds])
+    ref_loss.backward()
+    torch.testing.assert_close(loss.view(()), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+    for (name, p), q in zip(model.named_parameters(), ref_model.parameters()):
+        got, want = engine.gviews[p], q.grad
+        err = float((got - want).norm() / want.norm().clamp(min=1e-30))
+        # Both paths run the same pool contraction (P is bitwise equal, so the max routes to the
+        # same edges); what differs is the layer-0 forward's summation order (stream-K with
+        # atomics here, whole tiles there): a hidden unit on the ReLU kink is masked differently
+        # (tests/test_gpu_fullsize.py), which changes one row of dz0 — and through the pool
+        # routing a little of every row of the pool weight gradient (measured: 4.5e-4 of the
+        # norm, 2 % of the elements beyond 2e-3 of their value, max |diff| 6e-7 of max 8e-4)
+        assert err < 2e-3, (name, err)
+        off = (got - want).abs() > 1e-7 + 2e-3 * want.abs()
+        assert int(off.sum()) <= 0.05 * off.numel(), (name, int(off.sum()))
+    opt.step()
+    for (name, p), q in zip(model.named_parameters(), ref_model.parameters()):
+        # Adam's first step moves every element by ~lr * sign(g): elements whose tiny gradient
+        # differs in sign between the paths move in opposite directions (2 lr apart)
+        off = (p.data - q.data).abs() > 1e-6 + 1e-4 * q.data.abs()
+        assert int(off.sum()) <= 0.01 * off.numel(), (name, int(off.sum()))
+    # the dP buffers were handed back zeroed for the next step's scatter
+    for a in engine.act:
+        assert float(a['dP'].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("n_in", [25, 5])
 def test_reddit_shape_lstm_layer_matches_torch_lstmcell(reddit, dev, n_in):
     """The lstm aggregator's layer at the Reddit shape (T = seeds + hop-1 nodes ~ 12.4 k targets,

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("aggregator", ["mean", "sum", "max"])
+@pytest.mark.parametrize("aggregator", ["mean", "sum", "max", "max_pool", "mean_pool"])
 def test_engine_matches_module_path(dev, aggregator):
     from graphsage_amd.datasets import planted_partition
     from graphsage_amd.engine import SageTrainEngine

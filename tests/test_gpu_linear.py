@@ -370,3 +370,54 @@ def test_fusion_flags(dev):
         ops.adam_step(pb, gb, mb, vb, steps_b[par:par + 1], 1e-2, step_out=steps_b[1 - par:2 - par], zero_grad=True)
         assert torch.equal(ga, gr.to(dev)) and float(gb.abs().max()) == 0.0
     assert torch.equal(pa, pb) and int(step_a) == 3 and int(steps_b.max()) == 3
+
+
+def test_relu_bwd_matches_threshold_backward(dev):
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    for n, ld in ((602, 608), (37, 37), (256, 256)):
+        m = 300
+        out = torch.randn(m, ld, generator=g, device=dev)[:, :n].relu()
+        dout = torch.randn(m, ld, generator=g, device=dev)[:, :n]
+        want = torch.ops.aten.threshold_backward(dout, out, 0.0)
+        keep = dout.clone()
+        count = torch.tensor([257], dtype=torch.int64, device=dev)
+        dz = torch.full((m, ld), 7.0, device=dev)[:, :n]
+        ops.relu_bwd(dout, out, m=m, m_dev=count, dz=dz, clear_dout=True)
+        assert torch.equal(dz[:257], want[:257])
+        assert float(dz[257:].min()) == 7.0                      # rows beyond the device count untouched
+        assert float(dout[:257].abs().max()) == 0.0              # consumed rows handed back zeroed
+        assert torch.equal(dout[257:], keep[257:])
+
+
+def test_dweight_device_count_far_below_capacity(dev):
+    """Weight gradients whose contraction length is a device-side count well below the capacity
+    the grid was sized for (the pooling aggregators: all sampled nodes, capacity 141k, ~81k
+    sampled): the slices of the split deal the ACTUAL length, the result is that of the short
+    contraction."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(4)
+    cap, m, n, k = 9000, 3100, 96, 200
+    dout = torch.randn(cap, n, generator=g, device=dev)
+    a = torch.randn(cap, k, generator=g, device=dev)
+    count = torch.tensor([m], dtype=torch.int64, device=dev)
+    dw = torch.zeros(n, k, device=dev)
+    db = torch.zeros(n, device=dev)
+    ops.linear_dweight(dout, a, m=cap, m_dev=count, dw=dw, dbias=db)
+    want = dout[:m].double().t() @ a[:m].double()
+    torch.testing.assert_close(dw.double(), want, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.double(), dout[:m].double().sum(0), rtol=1e-4, atol=1e-3)
+    for mode in ("0", "1"):     # both contraction modes
+        import os
+        os.environ["SAGE_GEMM_X3"] = mode
+        try:
+            dw2 = torch.zeros(n, k, device=dev)
+            big_a = torch.randn(cap * 4, k, generator=g, device=dev)
+            big_d = torch.randn(cap * 4, n, generator=g, device=dev)
+            cnt = torch.tensor([cap * 4 * 57 // 100], dtype=torch.int64, device=dev)
+            ops.linear_dweight(big_d, big_a, m=cap * 4, m_dev=cnt, dw=dw2)
+            mm = int(cnt)
+            want2 = big_d[:mm].double().t() @ big_a[:mm].double()
+            torch.testing.assert_close(dw2.double(), want2, rtol=1e-4, atol=2e-3)
+        finally:
+            del os.environ["SAGE_GEMM_X3"]
