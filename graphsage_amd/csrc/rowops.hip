@@ -442,12 +442,16 @@ extern "C" int sage_relu_bwd(float* dout, sage_i64 ld_dout, const float* out, sa
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(dout && out && dz, SAGE_EINVAL, "sage_relu_bwd: NULL pointer argument");
   SAGE_REQUIRE(!clear_dout || dz != dout, SAGE_EINVAL, "sage_relu_bwd: clear_dout excludes dz aliasing dout");
-  const bool v4 = n % 4 == 0 && ld_dout % 4 == 0 && ld_out % 4 == 0 && ld_dz % 4 == 0 && vec16(dout) && vec16(out) &&
-                  vec16(dz);
-  const int64_t per_row = v4 ? n / 4 : n;
+  // 16-byte vectors over the width rounded up to 4 when every row stride covers it (padded rows,
+  // e.g. 602 columns in a stride of 608: the pad columns are rewritten with dout's pad values
+  // masked by out's — zeros stay zeros)
+  const int n4 = (n + 3) / 4 * 4;
+  const bool v4 = ld_dout % 4 == 0 && ld_out % 4 == 0 && ld_dz % 4 == 0 && ld_dout >= n4 && ld_out >= n4 &&
+                  ld_dz >= n4 && vec16(dout) && vec16(out) && vec16(dz);
+  const int64_t per_row = v4 ? n4 / 4 : n;
   const unsigned grid = static_cast<unsigned>(cdiv(m * per_row, kBlock));
   if (v4) {
-    relu_bwd_kernel<true><<<grid, kBlock, 0, stream>>>(dout, ld_dout, out, ld_out, m, m_dev, n, dz, ld_dz, clear_dout);
+    relu_bwd_kernel<true><<<grid, kBlock, 0, stream>>>(dout, ld_dout, out, ld_out, m, m_dev, n4, dz, ld_dz, clear_dout);
   } else {
     relu_bwd_kernel<false><<<grid, kBlock, 0, stream>>>(dout, ld_dout, out, ld_out, m, m_dev, n, dz, ld_dz, clear_dout);
   }
