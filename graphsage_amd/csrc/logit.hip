@@ -1,0 +1,476 @@
+// The class-logit layer of the supervised step in two launches (the last SAGE layer acts on the B
+// seed rows only: 512 targets, <= 25 sources each, C = 41 outputs — ~0.1 GFLOP and ~30 MB, a chain
+// of short dependent kernels when it is run as gather / GEMM / normalise+loss / d-input / scatter).
+//
+//   forward  (one wave per seed, the [C, 2H] weights staged in LDS once per workgroup):
+//     agg = reduce_{e in seg(t)} h[src[e]]                          layers/sage.py:136-137, 209-210
+//     z   = agg . W_l^T + h[t] . W_r^T                               layers/sage.py:124-129
+//     y   = z / max(|z|, eps);  CE(y, label);  dz = d loss / d z     layers/sage.py:131-132,
+//                                                                    fig2a/runners/graphsage_runners.py:43
+//   backward (one wave per seed, same staging):
+//     dh[src[e]] += (dz . W_l) / deg   for the segment's edges,   dh[t] += dz . W_r
+//     (what autograd derives for the two Linears and the scatter; lane l owns columns l + 64 k, so
+//     every atomic wave-instruction adds 256 contiguous bytes of one row)
+//     and loss = mean(row_loss), reduced by the first wave in a fixed order.
+// The weight gradients stay with sage_linear_dweight2 (they need agg, which the forward keeps).
+#include "common.h"
+
+namespace sage {
+namespace {
+
+#ifdef SAGE_LOGIT_PROF      // diagnostic build (scratch/logit_prof.hip): cycle stamps per phase, never in the library
+__device__ unsigned long long g_logit_prof[2][16];
+#define LOGIT_STAMP(k, i) do { if (threadIdx.x == 0 && blockIdx.x == 3) g_logit_prof[k][i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LOGIT_STAMP(k, i) do { } while (0)
+#endif
+
+constexpr int kLogitBlock = 256;                       // 4 seeds per workgroup, one wave per SIMD (the products are VALU work)
+constexpr int kLogitWaves = kLogitBlock / kWave;
+constexpr float kNormEps = 1e-12f;                     // torch.nn.functional.normalize default
+constexpr int kRowRegs = 16;         // float4 registers of gathered rows in flight per lane (1 KB rows from L2 /
+                                     // MALL, latency-bound: 16 rows of 256 floats at once)
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ inline int64_t readlane64(int64_t v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(static_cast<int>(v & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane(static_cast<int>(v >> 32), lane);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
+// Both kernels are chains of dependent memory round trips (segment bounds -> neighbour ids -> rows
+// -> ...), so everything independent is requested up front: the [n, 2h] weights go to LDS as
+// lds[c][2 H] (row c = [W_l[c, :] | W_r[c, :]]) through registers, the loads of the first batch
+// issued together at the top of the kernel and stored once the chain has something else in
+// flight.  A pass covers 512 / (h / 4) whole rows of one matrix, thread -> (row in pass, float4
+// in row) fixed for the kernel: one division per thread, no per-load address select (the first
+// version computed (row, column, matrix) per load: 1,000 instructions of branches and divisions,
+// 7 of the forward kernel's 17.7 us).
+constexpr int kStageBatch = 11;      // passes per matrix in flight: 11 x 4 rows covers n = 41 at h = 256
+struct WeightStage {
+  float4 vl[kStageBatch], vr[kStageBatch];
+  int r, q, rpp;                     // row within a pass, float4 within the row, rows per pass
+  bool active;
+  __device__ inline void init(int quads) {
+    rpp = kLogitBlock / quads;
+    if (rpp < 1) rpp = 1;            // (quads <= 256 by the entry point's width limit)
+    r = threadIdx.x / quads;
+    q = threadIdx.x - r * quads;
+    active = r < rpp;
+  }
+  __device__ inline void load(int pass0, int n, const float* __restrict__ w_l, int64_t ld_wl,
+                              const float* __restrict__ w_r, int64_t ld_wr) {
+#pragma unroll
+    for (int b = 0; b < kStageBatch; ++b) {
+      int c = (pass0 + b) * rpp + r;
+      if (c >= n) c = n - 1;         // clamped, not branched: the loads stay one batch
+      vl[b] = *reinterpret_cast<const float4*>(w_l + c * ld_wl + q * 4);
+      vr[b] = *reinterpret_cast<const float4*>(w_r + c * ld_wr + q * 4);
+    }
+  }
+  __device__ inline void store(float* lds, int pass0, int n, int h) const {
+#pragma unroll
+    for (int b = 0; b < kStageBatch; ++b) {
+      const int c = (pass0 + b) * rpp + r;
+      if (active && c < n) {
+        float* row = lds + static_cast<int64_t>(c) * 2 * h + q * 4;
+        *reinterpret_cast<float4*>(row) = vl[b];
+        *reinterpret_cast<float4*>(row + h) = vr[b];
+      }
+    }
+  }
+  // the batches after the first (n above 6 passes of rows)
+  __device__ inline void rest(float* lds, int n, int h, const float* __restrict__ w_l, int64_t ld_wl,
+                              const float* __restrict__ w_r, int64_t ld_wr) {
+    for (int pass0 = kStageBatch; pass0 * rpp < n; pass0 += kStageBatch) {
+      load(pass0, n, w_l, ld_wl, w_r, ld_wr);
+      store(lds, pass0, n, h);
+    }
+  }
+};
+
+// NV = H / 256 (a lane holds NV float4 of a row: columns 4 (lane + 64 v) ..)
+template <int NV, bool FULL>      // FULL: h == 256 NV, no lane is ever out of the row
+__global__ void __launch_bounds__(kLogitBlock)
+logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
+                 const int64_t* __restrict__ src, int64_t m, int h, int mean,
+                 const float* __restrict__ w_l, int64_t ld_wl, const float* __restrict__ w_r, int64_t ld_wr,
+                 int n, const int64_t* __restrict__ labels, const int64_t* __restrict__ label_rows,
+                 float grad_scale, float* __restrict__ agg, int64_t ld_agg, float* __restrict__ y, int64_t ld_y,
+                 float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
+                 float* __restrict__ row_loss) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kLogitWaves + threadIdx.x / kWave;
+  const bool live = t < m;      // wave-uniform; every wave takes part in the staging and the barrier
+  const int nq = h / 4;         // float4 per row
+  constexpr int kRowsInFlight = kRowRegs / NV;
+  auto in_row = [&](int v) { return FULL || lane + kWave * v < nq; };
+
+  LOGIT_STAMP(0, 0);
+  float4 acc[NV], root[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) acc[v] = root[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // requests in the order their results are needed; none waits for another except where noted
+  const int64_t tc = live ? t : m - 1;                 // (dead waves of the last workgroup: clamped, results unused)
+  const int64_t s0 = seg_ptr[tc];
+  const int64_t len = seg_ptr[tc + 1] - s0;
+  const int64_t lab_row = label_rows != nullptr ? label_rows[tc] : tc;
+  {
+    const float4* rp = reinterpret_cast<const float4*>(hrows + tc * ld_h);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (in_row(v)) root[v] = rp[lane + kWave * v];
+    }
+  }
+  int64_t my0 = 0;
+  if (lane < len) my0 = src[s0 + lane];                // needs s0: the chain's second round trip
+  WeightStage st;                                      // requested behind it, stored while the rows travel
+  st.init(nq);
+  st.load(0, n, w_l, ld_wl, w_r, ld_wr);
+  const int64_t lab = labels[lab_row];                 // needs lab_row
+  LOGIT_STAMP(0, 1);
+  bool staged = false;
+  if (live) {
+    for (int64_t base = 0; base < len; base += kWave) {
+      const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
+      int64_t my = my0;
+      if (base > 0) {
+        my = 0;
+        if (lane < chunk) my = src[s0 + base + lane];
+      }
+      for (int r0 = 0; r0 < chunk; r0 += kRowsInFlight) {
+        float4 x[kRowsInFlight][NV];
+#pragma unroll
+        for (int r = 0; r < kRowsInFlight; ++r) {
+          if (r0 + r < chunk) {
+            const float4* rowp = reinterpret_cast<const float4*>(hrows + readlane64(my, r0 + r) * ld_h);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              if (in_row(v)) x[r][v] = rowp[lane + kWave * v];
+            }
+          }
+        }
+        if (!staged) {       // (first round of rows requested: now the weights, which arrived before them)
+          st.store(wlds, 0, n, h);
+          staged = true;
+        }
+#pragma unroll
+        for (int r = 0; r < kRowsInFlight; ++r) {
+          if (r0 + r < chunk) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              if (in_row(v)) {
+                acc[v].x += x[r][v].x;
+                acc[v].y += x[r][v].y;
+                acc[v].z += x[r][v].z;
+                acc[v].w += x[r][v].w;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (mean) {
+      const float cnt = len > 0 ? static_cast<float>(len) : 1.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        acc[v].x /= cnt;
+        acc[v].y /= cnt;
+        acc[v].z /= cnt;
+        acc[v].w /= cnt;
+      }
+    }
+    float4* ap = reinterpret_cast<float4*>(agg + t * ld_agg);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (in_row(v)) ap[lane + kWave * v] = acc[v];
+    }
+  }
+  if (!staged) st.store(wlds, 0, n, h);      // dead waves and seeds without neighbours
+  st.rest(wlds, n, h, w_l, ld_wl, w_r, ld_wr);
+  LOGIT_STAMP(0, 2);
+  LOGIT_STAMP(0, 3);
+  __syncthreads();
+  LOGIT_STAMP(0, 4);
+  if (!live) return;
+
+  // z[c] = <agg, W_l[c]> + <h[t], W_r[c]>: every lane forms its share of all 64 (n, zero-padded)
+  // products, then ONE transposing butterfly sums them: at the step with distance o a lane keeps
+  // the half of its values whose index has bit o set like its own lane id and adds the partner's
+  // copy of that half — 32 + 16 + ... + 1 = 63 exchanges instead of 6 per output, and lane c ends
+  // up with z[c].  (A butterfly per output costs 6 n dependent ds_bpermute: 9 of this kernel's
+  // 22 us when it was written that way.)
+  float p[64];
+#pragma unroll
+  for (int c0 = 0; c0 < 64; c0 += 8) {
+    if (c0 < n) {       // wave-uniform; inside a group nothing is conditional, so its 16 LDS reads are in flight together
+      float4 a[8][NV], b[8][NV];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j < n ? c0 + j : n - 1;
+        const float4* wl = reinterpret_cast<const float4*>(wlds + static_cast<int64_t>(c) * 2 * h);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int col = in_row(v) ? lane + kWave * v : 0;
+          a[j][v] = wl[col];
+          b[j][v] = wl[nq + col];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          float qq = acc[v].x * a[j][v].x + acc[v].y * a[j][v].y + acc[v].z * a[j][v].z + acc[v].w * a[j][v].w;
+          qq += root[v].x * b[j][v].x + root[v].y * b[j][v].y + root[v].z * b[j][v].z + root[v].w * b[j][v].w;
+          q += in_row(v) ? qq : 0.f;
+        }
+        p[c0 + j] = c0 + j < n ? q : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) p[c0 + j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const bool up = (lane & o) != 0;
+#pragma unroll
+    for (int j = 0; j < o; ++j) {
+      const float send = up ? p[j] : p[j + o];
+      const float keep = up ? p[j + o] : p[j];
+      p[j] = keep + __shfl_xor(send, o);
+    }
+  }
+  const float zc = p[0];
+  LOGIT_STAMP(0, 5);
+  // normalise + cross entropy + d loss / d z on the n <= 64 values, one per lane (the formulas of
+  // logits_xent_fused_kernel, rowops.hip)
+  const bool has = lane < n;
+  const float ss = wave_sum(has ? zc * zc : 0.f);
+  const float denom = fmaxf(sqrtf(ss), kNormEps);
+  const float inv = 1.f / denom;
+  const bool clamped = inv >= 1.f / kNormEps;
+  const float yv = zc / denom;
+  const float mx = wave_max(has ? yv : -INFINITY);
+  const float se = wave_sum(has ? expf(yv - mx) : 0.f);
+  const float lse = mx + logf(se);
+  const float scale = grad_scale / static_cast<float>(m);
+  float g = has ? expf(yv - lse) : 0.f;
+  if (has && lane == lab) g -= 1.f;
+  g *= scale;
+  const float at_label = wave_sum(has && lane == lab ? yv : 0.f);
+  const float dot = clamped ? 0.f : wave_sum(has ? yv * g : 0.f);
+  if (lane == 0) {
+    if (inv_norm != nullptr) inv_norm[t] = inv;
+    row_loss[t] = (lab >= 0 && lab < n) ? lse - at_label : 0.f;
+  }
+  if (has) {
+    if (y != nullptr) y[t * ld_y + lane] = yv;
+    dz[t * ld_dz + lane] = (g - yv * dot) * inv;
+  }
+  LOGIT_STAMP(0, 6);
+}
+
+// NC = H / 64 (a lane owns columns lane + 64 k)
+template <int NC, bool FULL>      // FULL: h == 64 NC
+__global__ void __launch_bounds__(kLogitBlock)
+logit_bwd_kernel(const float* __restrict__ dz, int64_t ld_dz, const int64_t* __restrict__ seg_ptr,
+                 const int64_t* __restrict__ src, int64_t m, int h, int mean,
+                 const float* __restrict__ w_l, int64_t ld_wl, const float* __restrict__ w_r, int64_t ld_wr,
+                 int n, float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ row_loss,
+                 float* __restrict__ loss) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kLogitWaves + wave;
+  const bool live = t < m;
+  LOGIT_STAMP(1, 0);
+  const int64_t tc = live ? t : m - 1;
+  const int64_t s0 = seg_ptr[tc];
+  const int64_t len = seg_ptr[tc + 1] - s0;
+  float dzc = 0.f;
+  if (lane < n) dzc = dz[tc * ld_dz + lane];
+  int64_t my0 = 0;
+  if (lane < len) my0 = src[s0 + lane];                // needs s0
+  WeightStage st;
+  st.init(h / 4);
+  st.load(0, n, w_l, ld_wl, w_r, ld_wr);
+  st.store(wlds, 0, n, h);
+  st.rest(wlds, n, h, w_l, ld_wl, w_r, ld_wr);
+  if (loss != nullptr && blockIdx.x == 0 && wave == 0) {
+    // loss = mean(row_loss[0 : m]): lane l adds rows l, l + 64, ... in order, then the butterfly
+    float s = 0.f;
+    for (int64_t i = lane; i < m; i += kWave) s += row_loss[i];
+    s = wave_sum(s);
+    if (lane == 0) loss[0] = s / static_cast<float>(m);
+  }
+  LOGIT_STAMP(1, 1);
+  __syncthreads();
+  LOGIT_STAMP(1, 2);
+  if (!live) return;
+  float da[NC], dr[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) da[k] = dr[k] = 0.f;
+  for (int c0 = 0; c0 < n; c0 += 8) {      // eight outputs at a time: their LDS reads are in flight together
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j < n ? c0 + j : n - 1;
+      float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dzc), c));   // c is wave-uniform
+      if (c0 + j >= n) d = 0.f;
+      const float* wl = wlds + static_cast<int64_t>(c) * 2 * h;
+      const float* wr = wl + h;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (FULL || lane + kWave * k < h) {
+          da[k] += d * wl[lane + kWave * k];
+          dr[k] += d * wr[lane + kWave * k];
+        }
+      }
+    }
+  }
+  LOGIT_STAMP(1, 3);
+  float* rootp = dh + t * ld_dh;
+#pragma unroll
+  for (int k = 0; k < NC; ++k) {
+    if (FULL || lane + kWave * k < h) atomicAdd(rootp + lane + kWave * k, dr[k]);
+  }
+  if (len <= 0) return;
+  if (mean) {
+    const float cnt = static_cast<float>(len);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) da[k] /= cnt;
+  }
+  for (int64_t base = 0; base < len; base += kWave) {
+    const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
+    int64_t my = my0;
+    if (base > 0) {
+      my = 0;
+      if (lane < chunk) my = src[s0 + base + lane];
+    }
+    for (int r = 0; r < chunk; ++r) {
+      float* rowp = dh + readlane64(my, r) * ld_dh;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) {
+        if (FULL || lane + kWave * k < h) atomicAdd(rowp + lane + kWave * k, da[k]);
+      }
+    }
+  }
+  LOGIT_STAMP(1, 4);
+}
+
+inline bool vec16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_common(const char* who, sage_i64 m, int h, int n, int reduce, const float* w_l, sage_i64 ld_wl,
+                 const float* w_r, sage_i64 ld_wr, size_t* lds_bytes) {
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM, SAGE_EINVAL, "%s: reduce must be mean or sum", who);
+  SAGE_REQUIRE(m > 0 && n > 0 && h > 0, SAGE_EINVAL, "%s: bad shape (m=%lld h=%d n=%d)", who, (long long)m, h, n);
+  SAGE_REQUIRE(n <= kWave && h % 4 == 0 && h <= 1024, SAGE_ELIMIT,
+               "%s: needs at most 64 outputs and a width that is a multiple of 4, at most 1024 (n=%d h=%d)", who, n, h);
+  SAGE_REQUIRE(w_l && w_r && ld_wl >= h && ld_wr >= h && ld_wl % 4 == 0 && ld_wr % 4 == 0 && vec16(w_l) && vec16(w_r),
+               SAGE_EINVAL, "%s: weights must be 16-byte aligned rows of at least h floats", who);
+  *lds_bytes = static_cast<size_t>(n) * 2 * h * sizeof(float);
+  SAGE_REQUIRE(*lds_bytes <= 160 * 1024, SAGE_ELIMIT, "%s: the [n, 2h] weights (%zu bytes) do not fit the 160 KB of LDS", who,
+               *lds_bytes);
+  return SAGE_OK;
+}
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes, const char* who) {
+  // above 64 KB of dynamic LDS a kernel has to opt in, once per device (the attribute is kept
+  // at the device's maximum, so the size of a later call never exceeds it)
+  static bool done[64] = {};
+  if (bytes <= 64 * 1024) return SAGE_OK;
+  int dev = 0;
+  SAGE_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, SAGE_ELAUNCH, "%s: cannot query the device", who);
+  if (!done[dev]) {
+    SAGE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024) == hipSuccess,
+                 SAGE_ELAUNCH, "%s: cannot raise the dynamic LDS limit", who);
+    done[dev] = true;
+  }
+  return SAGE_OK;
+}
+
+}  // namespace
+}  // namespace sage
+
+using namespace sage;
+
+extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
+                                    sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                                    const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
+                                    const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
+                                    float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                                    float* row_loss, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  size_t lds = 0;
+  const int rc = check_common("sage_logit_layer_fwd", m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
+  if (rc != SAGE_OK) return rc;
+  SAGE_REQUIRE(h_rows && seg_ptr && src && labels && agg && dz && row_loss, SAGE_EINVAL,
+               "sage_logit_layer_fwd: NULL pointer argument");
+  SAGE_REQUIRE(ld_h >= h && ld_h % 4 == 0 && vec16(h_rows) && ld_agg >= h && ld_agg % 4 == 0 && vec16(agg) && ld_dz >= n &&
+                   (y == nullptr || ld_y >= n),
+               SAGE_EINVAL, "sage_logit_layer_fwd: rows of h / agg must be 16-byte aligned, ld_dz / ld_y >= n");
+  const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
+  const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
+#define SAGE_LOGIT_FWD(NV, FULL)                                                                                \
+  do {                                                                                                      \
+    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL>, lds, "sage_logit_layer_fwd");                     \
+    if (rc2 != SAGE_OK) return rc2;                                                                         \
+    logit_fwd_kernel<NV, FULL><<<grid, kLogitBlock, lds, stream>>>(h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, \
+                                                                   w_r, ld_wr, n, labels, label_rows, grad_scale, agg, \
+                                                                   ld_agg, y, ld_y, inv_norm, dz, ld_dz, row_loss); \
+  } while (0)
+  const int nv = (h / 4 + kWave - 1) / kWave;
+  const bool full = h == nv * 4 * kWave;
+  if (nv == 1 && full) SAGE_LOGIT_FWD(1, true);
+  else if (nv == 1) SAGE_LOGIT_FWD(1, false);
+  else if (nv == 2 && full) SAGE_LOGIT_FWD(2, true);
+  else if (nv == 2) SAGE_LOGIT_FWD(2, false);
+  else SAGE_LOGIT_FWD(4, false);
+#undef SAGE_LOGIT_FWD
+  SAGE_CHECK_LAUNCH("logit_fwd_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
+                                    sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                                    const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,
+                                    const float* row_loss, float* loss, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  size_t lds = 0;
+  const int rc = check_common("sage_logit_layer_bwd", m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
+  if (rc != SAGE_OK) return rc;
+  SAGE_REQUIRE(dz && seg_ptr && src && dh && ld_dz >= n && ld_dh >= h, SAGE_EINVAL,
+               "sage_logit_layer_bwd: NULL pointer argument or row stride below the width");
+  SAGE_REQUIRE((loss == nullptr) == (row_loss == nullptr), SAGE_EINVAL,
+               "sage_logit_layer_bwd: pass row_loss and loss together (or neither)");
+  const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
+  const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
+#define SAGE_LOGIT_BWD(NC, FULL)                                                                                \
+  do {                                                                                                      \
+    const int rc2 = allow_lds(logit_bwd_kernel<NC, FULL>, lds, "sage_logit_layer_bwd");                     \
+    if (rc2 != SAGE_OK) return rc2;                                                                         \
+    logit_bwd_kernel<NC, FULL><<<grid, kLogitBlock, lds, stream>>>(dz, ld_dz, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, \
+                                                                   ld_wr, n, dh, ld_dh, row_loss, loss);    \
+  } while (0)
+  const int nc = (h + kWave - 1) / kWave;
+  if (h == 256) SAGE_LOGIT_BWD(4, true);
+  else if (nc <= 4) SAGE_LOGIT_BWD(4, false);
+  else if (nc <= 8) SAGE_LOGIT_BWD(8, false);
+  else SAGE_LOGIT_BWD(16, false);
+#undef SAGE_LOGIT_BWD
+  SAGE_CHECK_LAUNCH("logit_bwd_kernel");
+  return SAGE_OK;
+}

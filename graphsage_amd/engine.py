@@ -14,6 +14,8 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
   * all gradients live in one flat buffer (one all-reduce under data parallelism, one Adam
     launch).
 """
+import os
+
 import torch
 
 from . import _lib, ops
@@ -97,6 +99,14 @@ class SageTrainEngine:
             raise NotImplementedError("engine: the pooling aggregators run the supervised (fig2a) step only")
         if self.pool:
             overlap_gather = False    # the layer-0 gather reads P, which needs this step's weights
+        # The class-logit layer (the last SAGE layer on the B seed rows) in one launch each way
+        # (sage_logit_layer_fwd / _bwd) instead of gather / split-K contraction / fused loss and
+        # d-input pair / scatter-add / loss mean: supervised step, mean or sum, two or more layers
+        last_w = model.layers[-1].lin_l.weight
+        # SAGE_NO_FUSED_LOGIT=1 keeps the separate kernels (the A/B switch of scratch/hb.sh)
+        self.fused_logit = (not os.environ.get('SAGE_NO_FUSED_LOGIT') and not unsup and not self.pool
+                            and self.root and self.reduce in ('mean', 'sum') and len(model.layers) >= 2
+                            and ops.logit_layer_supported(last_w.size(1), last_w.size(0)))
         self.features, self.labels = features, labels
         self.B = int(batch_size)
         self.L = len(model.layers)
@@ -413,8 +423,8 @@ class SageTrainEngine:
             self.make_pos_neg(slot, self.slot_counter[slot])
 
         def both():
-            self._forward(slot, skip_gather0)
-            self._backward(slot)
+            self._forward(slot, skip_gather0, fused=self.fused_logit)
+            self._backward(slot, fused=self.fused_logit)
         self._taped('fb%d' % skip_gather0, slot, both)
 
     def forward(self, slot=0, skip_gather0=False):
@@ -434,13 +444,15 @@ class SageTrainEngine:
     def _agg0(self, slot, v):
         return self.agg0[slot] if v == 0 else self.acts[v][0]['agg']
 
-    def _forward_layers(self, slot, v, skip_gather0):
-        """Layers of variant v up to the un-normalised logits z."""
+    def _forward_layers(self, slot, v, skip_gather0, upto=None):
+        """Layers of variant v up to the un-normalised logits z (or only the first `upto`)."""
         L, buf = self.L, self.bufs[slot]
         act = self.acts[v]
         x, node_map = self.features, self._node_map(slot, v)
         lib = ops
         for i, layer in enumerate(self.model.layers):
+            if upto is not None and i >= upto:
+                break
             a = act[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
             agg = self._agg0(slot, v) if i == 0 else a['agg']
@@ -469,8 +481,16 @@ class SageTrainEngine:
                                     clear_z=True)
             x, node_map = a.get('h'), None
 
-    def _forward(self, slot, skip_gather0):
+    def _forward(self, slot, skip_gather0, fused=False):
         buf, lib, B = self.bufs[slot], ops, self.B
+        if fused:
+            # (training step only: the loss mean then comes out of the backward launch)
+            self._forward_layers(slot, 0, skip_gather0, upto=self.L - 1)
+            last, layer = self.act[-1], self.model.layers[-1]
+            lib.logit_layer_fwd(self.act[-2]['h'], buf.seg_ptr, buf.src, B, self.reduce, layer.lin_l.weight,
+                                layer.lin_r.weight, self.labels, buf.node, last['agg'], last['y'], last['inv'],
+                                last['dz'], self.row_loss)
+            return
         if not self.unsup:
             self._forward_layers(slot, 0, skip_gather0)
             # last layer: normalise + cross-entropy on the seed rows + gradient w.r.t. z, one kernel
@@ -498,13 +518,13 @@ class SageTrainEngine:
             last = self.acts[v][-1]
             lib.l2norm_relu_bwd(last['dy'], last['y'], last['inv'], False, m=B, dz=last['dz'])
 
-    def _backward(self, slot):
+    def _backward(self, slot, fused=False):
         if self.keep_grads:
             _lib.tape_py(self.grad.zero_)
         for v in range(3 if self.unsup else 1):
-            self._backward_layers(slot, v)
+            self._backward_layers(slot, v, fused)
 
-    def _backward_layers(self, slot, v):
+    def _backward_layers(self, slot, v, fused=False):
         L, buf = self.L, self.bufs[slot]
         act = self.acts[v]
         lib = ops
@@ -527,6 +547,9 @@ class SageTrainEngine:
                 lib.linear_dweight(a['dz'], agg_i, m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
             if self.pool:
                 self._pool_backward(slot, i, x_in, rows)
+            elif fused and i == L - 1:
+                lib.logit_layer_bwd(a['dz'], buf.seg_ptr, buf.src, self.B, self.reduce, layer.lin_l.weight,
+                                    layer.lin_r.weight, act[i - 1]['dh'], self.row_loss, self.loss)
             elif i > 0:
                 prev = act[i - 1]
                 if self.root:

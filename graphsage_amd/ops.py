@@ -690,6 +690,61 @@ def logits_xent_fused(z, labels, label_rows, m, y, inv_norm, dz, row_loss, loss,
     _lib.check(rc, "sage_logits_xent_fused")
 
 
+def logit_layer_supported(h, n):
+    """Whether sage_logit_layer_fwd / _bwd take a [n, h] + [n, h] weight pair (n outputs, width h)."""
+    return n <= 64 and h % 4 == 0 and h <= 1024 and n * 2 * h * 4 <= 160 * 1024
+
+
+def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_rows, agg, y, inv_norm, dz,
+                    row_loss, grad_scale=1.0):
+    """The last SAGE layer on the m seed rows + normalise + cross entropy + d loss / d z in one
+    launch (reference layers/sage.py:99-134 + fig2a/runners/graphsage_runners.py:41-43); all
+    buffers are the caller's (static-shape engine).  agg [m, h] is kept for the weight gradients."""
+    lib = _lib.load()
+    hp, ld_h = _mat(h_rows, "h_rows")
+    wlp, ld_wl = _mat(w_l, "w_l")
+    wrp, ld_wr = _mat(w_r, "w_r")
+    n, h = w_l.shape
+    m = int(m)
+    ap, ld_agg = _mat(agg, "agg")
+    dp, ld_dz = _mat(dz, "dz")
+    yp, ld_y = (None, 0) if y is None else _mat(y, "y")
+    if h_rows.size(1) != h or tuple(w_r.shape) != (n, h) or m <= 0 or h_rows.size(0) < m or agg.size(0) < m \
+            or agg.size(1) != h or dz.size(0) < m or dz.size(1) != n or row_loss.numel() < m \
+            or seg_ptr.numel() < m + 1 or (y is not None and (y.size(0) < m or y.size(1) != n)) \
+            or (inv_norm is not None and inv_norm.numel() < m) \
+            or (label_rows is not None and label_rows.numel() < m) or (label_rows is None and labels.numel() < m):
+        raise RuntimeError("logit_layer_fwd: bad buffers")
+    rc = lib.sage_logit_layer_fwd(hp, ld_h, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), m, h,
+                                  REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n, _vec(labels, torch.int64, "labels"),
+                                  _vec(label_rows, torch.int64, "label_rows", allow_none=True), float(grad_scale),
+                                  ap, ld_agg, yp, ld_y, _vec(inv_norm, torch.float32, "inv_norm", allow_none=True),
+                                  dp, ld_dz, _vec(row_loss, torch.float32, "row_loss"), _stream())
+    _lib.check(rc, "sage_logit_layer_fwd")
+
+
+def logit_layer_bwd(dz, seg_ptr, src, m, reduce, w_l, w_r, dh, row_loss=None, loss=None):
+    """dh[src[e]] += (dz[t] @ w_l) (/ deg for mean), dh[t] += dz[t] @ w_r for the m seed rows, and
+    loss = mean(row_loss[:m]) if both are given — one launch (sage_linear_dinput2 +
+    sage_gather_reduce_bwd + the loss mean)."""
+    lib = _lib.load()
+    dp, ld_dz = _mat(dz, "dz")
+    wlp, ld_wl = _mat(w_l, "w_l")
+    wrp, ld_wr = _mat(w_r, "w_r")
+    n, h = w_l.shape
+    m = int(m)
+    hp, ld_dh = _mat(dh, "dh")
+    if tuple(w_r.shape) != (n, h) or dz.size(0) < m or dz.size(1) != n or dh.size(1) != h or dh.size(0) < m \
+            or seg_ptr.numel() < m + 1 or (row_loss is None) != (loss is None) \
+            or (row_loss is not None and row_loss.numel() < m):
+        raise RuntimeError("logit_layer_bwd: bad buffers")
+    rc = lib.sage_logit_layer_bwd(dp, ld_dz, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), m, h,
+                                  REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n, hp, ld_dh,
+                                  _vec(row_loss, torch.float32, "row_loss", allow_none=True),
+                                  _p(loss, torch.float32, "loss", allow_none=True), _stream())
+    _lib.check(rc, "sage_logit_layer_bwd")
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8,
               weight_decay=0.0, grad_scale=1.0, step_out=None, zero_grad=False):
     """torch.optim.Adam step on flat fp32 buffers.  The step count is read from step_dev

@@ -379,6 +379,32 @@ int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* labels,
                            float* row_loss /*[m]*/, float* loss /*[1]*/,
                            int clear_z /* 1: z rows are zeroed after use */, void* stream);
 
+/* The class-logit layer of the supervised step — the last SAGE layer on the m seed rows
+ * (layers/sage.py:99-134 called from models/graphsage.py:44-49, sliced [:batch_size] at
+ * fig2a/runners/graphsage_runners.py:41-43) — in one launch each way, for reduce = mean or sum
+ * with a root weight, n <= 64 outputs, width h a multiple of 4 and <= 1024, n * 2h * 4 bytes of
+ * weights within the 160 KB of LDS (else SAGE_ELIMIT: run the separate entry points).
+ *   forward:  agg[t] = reduce_{e in [seg_ptr[t], seg_ptr[t+1])} h_rows[src[e]]   (kept for the
+ *             weight gradients);  z = agg[t] . w_l^T + h_rows[t] . w_r^T;  y = z / max(|z|, 1e-12);
+ *             row_loss[t] = CE(y, labels[label_rows ? label_rows[t] : t]);
+ *             dz[t] = grad_scale / m * d CE / d z   (exactly sage_gather_reduce_fwd +
+ *             sage_linear_concat_fwd + sage_logits_xent_fused without the loss mean; y, inv_norm
+ *             optional)
+ *   backward: dh[src[e]] += (dz[t] . w_l) (/ segment length for mean),  dh[t] += dz[t] . w_r
+ *             (sage_linear_dinput2 + sage_gather_reduce_bwd; dh is accumulated with fp32 atomics
+ *             and must hold zeros or a gradient to add to), and, if row_loss / loss are given,
+ *             loss[0] = mean(row_loss[0:m]) in a fixed order. */
+int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
+                         sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                         const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
+                         const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
+                         float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                         float* row_loss, void* stream);
+int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
+                         sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                         const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,
+                         const float* row_loss, float* loss, void* stream);
+
 /* (f-2) unsupervised loss of trainers/base_trainers.py:179-181 on m rows of width n:
  *   loss[0] = -mean logsigmoid(<out_i, pos_i>) - mean logsigmoid(-<out_i, neg_i>)
  * and its gradient times grad_scale: d_out is ACCUMULATED (it may already hold the supervised

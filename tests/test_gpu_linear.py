@@ -421,3 +421,74 @@ def test_dweight_device_count_far_below_capacity(dev):
             torch.testing.assert_close(dw2.double(), want2, rtol=1e-4, atol=2e-3)
         finally:
             del os.environ["SAGE_GEMM_X3"]
+
+
+@pytest.mark.parametrize("reduce,h,n", [("mean", 256, 41), ("sum", 64, 7), ("mean", 512, 40), ("mean", 36, 5)])
+def test_logit_layer_fused_matches_separate_kernels(dev, reduce, h, n):
+    """sage_logit_layer_fwd / _bwd against the chain they replace (gather_reduce_fwd ->
+    linear_concat_fwd -> logits_xent_fused; linear_dinput2 -> gather_reduce_bwd, loss mean) and
+    against plain torch autograd, on ragged segments including empty ones."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    m, n_src = 77, 400
+    ldh = (h + 15) // 16 * 16
+    hrows = torch.randn(n_src, ldh, generator=g, device=dev)[:, :h]
+    deg = torch.randint(0, 30, (m,), generator=g, device=dev)
+    deg[3] = 0
+    deg[5] = 70          # more than one wave of neighbours
+    seg_ptr = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    seg_ptr[1:] = deg.cumsum(0)
+    e = int(seg_ptr[-1])
+    src = torch.randint(0, n_src, (e,), generator=g, device=dev)
+    wbuf = torch.randn(2 * n, ldh, generator=g, device=dev) * 0.2
+    w_l, w_r = wbuf[:n, :h], wbuf[n:, :h]
+    node = torch.randperm(1000, generator=g, device=dev)[:m]
+    labels = torch.randint(0, n, (1000,), generator=g, device=dev)
+    # fused
+    agg = torch.zeros(m, ldh, device=dev)[:, :h]
+    y = torch.zeros(m, 64, device=dev)[:, :n]
+    dz = torch.zeros(m, 64, device=dev)[:, :n]
+    inv = torch.zeros(m, device=dev)
+    row_loss = torch.zeros(m, device=dev)
+    loss = torch.zeros(1, device=dev)
+    dh = torch.zeros(n_src, ldh, device=dev)[:, :h]
+    ops.logit_layer_fwd(hrows, seg_ptr, src, m, reduce, w_l, w_r, labels, node, agg, y, inv, dz, row_loss)
+    ops.logit_layer_bwd(dz, seg_ptr, src, m, reduce, w_l, w_r, dh, row_loss, loss)
+    # separate kernels
+    agg2, _ = ops.gather_reduce_fwd(hrows, seg_ptr, src, m, reduce)
+    z2 = ops.linear_concat_fwd(agg2, w_l, hrows, w_r, m=m)
+    y2, dz2, inv2 = torch.zeros_like(y), torch.zeros_like(dz), torch.zeros_like(inv)
+    rl2, loss2 = torch.zeros_like(row_loss), torch.zeros_like(loss)
+    ops.logits_xent_fused(z2, labels, node, m, y2, inv2, dz2, rl2, loss2)
+    dh2 = torch.zeros_like(dh)
+    dagg2 = torch.zeros(m, ldh, device=dev)[:, :h]
+    ops.linear_dinput2(dz2, w_r, dh2[:m], w_l, dagg2, m=m)
+    ops.gather_reduce_bwd(dagg2, seg_ptr, src, m, reduce, dh2)
+    assert torch.equal(agg, agg2)
+    torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(row_loss, rl2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss, loss2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dz, dz2, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(dh, dh2, rtol=1e-4, atol=1e-6)
+    # plain torch
+    hr = hrows.detach().clone().double().requires_grad_(True)
+    dst = torch.repeat_interleave(torch.arange(m, device=dev), deg)
+    a = torch.zeros(m, h, dtype=torch.float64, device=dev).index_add_(0, dst, hr[src])
+    if reduce == "mean":
+        a = a / deg.clamp(min=1).unsqueeze(1)
+    z = a @ w_l.double().t() + hr[:m] @ w_r.double().t()
+    want = F.cross_entropy(F.normalize(z, p=2.0, dim=-1), labels[node])
+    want.backward()
+    torch.testing.assert_close(loss.double().view(()), want.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dh.double(), hr.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_logit_layer_rejects_weights_beyond_lds(dev):
+    from graphsage_amd import ops
+    assert not ops.logit_layer_supported(512, 64) and ops.logit_layer_supported(512, 40)
+    z = torch.zeros(8, 512, device=dev)
+    w = torch.zeros(64, 512, device=dev)
+    seg = torch.zeros(9, dtype=torch.int64, device=dev)
+    with pytest.raises(RuntimeError, match="do not fit"):
+        ops.logit_layer_fwd(z, seg, seg, 8, "mean", w, w, seg, None, torch.zeros(8, 512, device=dev), None, None,
+                            torch.zeros(8, 64, device=dev), torch.zeros(8, device=dev))

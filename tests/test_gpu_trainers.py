@@ -159,13 +159,16 @@ def test_unsupervised_trainer_runs(dev, use_engine):
     assert tr.results[-1]['loss'] < tr.results[0]['loss'] + 0.1
 
 
-@pytest.mark.parametrize("aggregator", ["mean", "max_pool", "gcn"])
+@pytest.mark.parametrize("aggregator", ["mean", "max_pool", "gcn", "lstm"])
 def test_fig2a_harness(dev, aggregator):
     from graphsage_amd.experiments import fig2a
     ds = _dataset(noise=1.0)
+    if aggregator == "lstm":
+        from graphsage_amd import settings
+        settings.LSTM_NUM_INPUTS = 4
     out = fig2a.get(aggregator, dataset=ds, num_epochs=2, batch_size=128, k1=6, k2=4, verbose=False).run()
     assert set(out) >= {'test_time', 'train_time'}
-    assert out['engine'] == (aggregator in ("mean", "gcn"))
+    assert out['engine'] == (aggregator != "lstm")       # lstm trains through the module path
     assert out['train_time'] > 0 and out['test_time'] > 0 and out['test_acc'] > 0.5
 
 
