@@ -196,6 +196,8 @@ def bracket_contractions(ops):
         mm = rows_of(m, m_dev, rows1.numel() if rows1 is not None else a1.size(0))
         return 2.0 * mm * w1.size(0) * (w1.size(1) + (w2.size(1) if w2 is not None else 0))
     bracket("linear_concat_fwd", fwd_flops)
+    bracket("pool_linear_fwd", lambda x, w, bias, m=None, m_dev=None, rows=None, **kw:
+            2.0 * rows_of(m, m_dev, rows.numel() if rows is not None else x.size(0)) * w.size(0) * w.size(1))
     bracket("linear_dweight", lambda dout, a, m=None, m_dev=None, **kw:
             2.0 * rows_of(m, m_dev, dout.size(0)) * dout.size(1) * a.size(1))
     bracket("linear_dweight2", lambda dout, a1, dw1, a2, dw2, m=None, m_dev=None, **kw:

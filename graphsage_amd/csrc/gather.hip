@@ -309,6 +309,115 @@ __global__ void gather_max_bwd_kernel(const float* __restrict__ dout, int64_t ld
   }
 }
 
+// Backward of max over rows of P = relu(pool(x)), straight to the gradient of the pool Linear's
+// pre-activation: agg[t,f] = P[arg-max row, f], so agg[t,f] > 0 IS the relu mask of the element
+// the gradient is routed to — no pass over P, no dense d P.  One workgroup per target.
+__global__ void __launch_bounds__(kBlock)
+pool_max_bwd_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const float* __restrict__ agg,
+                    int64_t ld_agg, const int64_t* __restrict__ src, const int64_t* __restrict__ argmax,
+                    int64_t num_targets, const int64_t* __restrict__ num_targets_dev, int num_features,
+                    float* __restrict__ dpre, int64_t ld_dpre) {
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = blockIdx.x;
+  if (t >= nt) return;
+  for (int f = threadIdx.x; f < num_features; f += kBlock) {
+    const int64_t e = argmax[t * num_features + f];
+    const float gv = dagg[t * ld_dagg + f];
+    if (e >= 0 && agg[t * ld_agg + f] > 0.f) atomicAdd(dpre + src[e] * ld_dpre + f, gv);
+  }
+}
+
+// The same routing with the batch's source in-degrees at hand (indeg[s] = number of edges of the
+// live targets that start at row s): a row with ONE incoming edge is owned by that edge's target,
+// which writes the whole row with plain stores (the routed value or 0) — whole lines, no fetch, no
+// atomic; only rows shared by several targets take the atomic route (into zeros).
+__global__ void __launch_bounds__(kWave)
+pool_indeg_kernel(const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src, int64_t num_targets,
+                  const int64_t* __restrict__ num_targets_dev, int64_t num_sources, int* __restrict__ indeg) {
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = blockIdx.x;
+  if (t >= nt) return;
+  const int64_t s1 = seg_ptr[t + 1];
+  for (int64_t e = seg_ptr[t] + threadIdx.x; e < s1; e += kWave) {
+    const int64_t s = src[e];
+    if (s >= 0 && s < num_sources) atomicAdd(indeg + s, 1);
+  }
+}
+
+constexpr int kPoolCols = 4;   // columns per thread and pass
+__global__ void __launch_bounds__(kBlock)
+pool_max_bwd_rows_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const float* __restrict__ agg,
+                         int64_t ld_agg, const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src,
+                         const int64_t* __restrict__ argmax, int64_t num_targets,
+                         const int64_t* __restrict__ num_targets_dev, int num_features,
+                         int64_t num_sources, const int* __restrict__ indeg, float* __restrict__ dpre,
+                         int64_t ld_dpre) {
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = blockIdx.x;
+  if (t >= nt) return;
+  const int64_t s0 = seg_ptr[t], s1 = seg_ptr[t + 1];
+  for (int f0 = 0; f0 < num_features; f0 += kPoolCols * kBlock) {
+    int64_t ef[kPoolCols];
+    float gf[kPoolCols];
+#pragma unroll
+    for (int c = 0; c < kPoolCols; ++c) {
+      const int f = f0 + c * kBlock + threadIdx.x;
+      ef[c] = -1;
+      gf[c] = 0.f;
+      if (f < num_features) {
+        ef[c] = argmax[t * num_features + f];
+        const float gv = dagg[t * ld_dagg + f];
+        gf[c] = agg[t * ld_agg + f] > 0.f ? gv : 0.f;
+      }
+    }
+    for (int64_t e = s0; e < s1; ++e) {
+      const int64_t s = src[e];                     // workgroup-uniform
+      if (s < 0 || s >= num_sources) continue;
+      float* row = dpre + s * ld_dpre;
+      if (indeg[s] == 1) {
+#pragma unroll
+        for (int c = 0; c < kPoolCols; ++c) {
+          const int f = f0 + c * kBlock + threadIdx.x;
+          if (f < num_features) row[f] = ef[c] == e ? gf[c] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < kPoolCols; ++c) {
+          const int f = f0 + c * kBlock + threadIdx.x;
+          if (f < num_features && ef[c] == e && gf[c] != 0.f) atomicAdd(row + f, gf[c]);
+        }
+      }
+    }
+  }
+}
+
+// The pool bias gradient of the same step: every (t, f) lands in exactly one row of dpre, so the
+// column sums of dpre are the column sums of the masked dagg — 13k target rows instead of 81k
+// source rows (an empty segment has agg = 0, so agg > 0 alone says "routed and unmasked").
+// blockIdx.x: 256 columns, blockIdx.y: a chunk of rows; one atomic per column and chunk.
+constexpr int kPoolRowsPerBlock = 32;
+__global__ void __launch_bounds__(kBlock)
+pool_max_dbias_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const float* __restrict__ agg,
+                      int64_t ld_agg, int64_t num_targets, const int64_t* __restrict__ num_targets_dev,
+                      int num_features, float* __restrict__ dbias) {
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int f = blockIdx.x * kBlock + threadIdx.x;
+  const int64_t t0 = static_cast<int64_t>(blockIdx.y) * kPoolRowsPerBlock;
+  int64_t t1 = t0 + kPoolRowsPerBlock;
+  if (t1 > nt) t1 = nt;
+  if (f >= num_features || t0 >= t1) return;
+  float s0 = 0.f, s1 = 0.f;
+  int64_t t = t0;
+  for (; t + 1 < t1; t += 2) {
+    const float g0 = dagg[t * ld_dagg + f], g1 = dagg[(t + 1) * ld_dagg + f];
+    const float a0 = agg[t * ld_agg + f], a1 = agg[(t + 1) * ld_agg + f];
+    s0 += a0 > 0.f ? g0 : 0.f;
+    s1 += a1 > 0.f ? g1 : 0.f;
+  }
+  if (t < t1 && agg[t * ld_agg + f] > 0.f) s0 += dagg[t * ld_dagg + f];
+  atomicAdd(dbias + f, s0 + s1);
+}
+
 // ---------------------------------------------------------------- COO -> target CSR
 __global__ void iota_hist_kernel(const int64_t* __restrict__ edge_dst, int64_t num_edges,
                                  int64_t num_targets, int64_t* __restrict__ iota,
@@ -512,6 +621,45 @@ extern "C" int sage_gather_reduce_fwd_timed(const float* x, sage_i64 ld_x, const
                                 LaunchEvents{static_cast<hipEvent_t>(start_event),
                                              static_cast<hipEvent_t>(stop_event)},
                                 stream);
+}
+
+extern "C" int sage_pool_max_bwd(const float* dagg, sage_i64 ld_dagg, const float* agg, sage_i64 ld_agg,
+                                 const sage_i64* seg_ptr, const sage_i64* src, const sage_i64* argmax,
+                                 sage_i64 num_targets, const sage_i64* num_targets_dev, int num_features,
+                                 float* dpre, sage_i64 ld_dpre, sage_i64 num_sources, int* indeg,
+                                 float* dbias, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(num_features > 0 && ld_dagg >= num_features && ld_agg >= num_features &&
+                   ld_dpre >= num_features && num_targets >= 0 && num_sources >= 0,
+               SAGE_EINVAL, "sage_pool_max_bwd: bad shape");
+  if (num_targets == 0) return SAGE_OK;
+  SAGE_REQUIRE(dagg && agg && src && argmax && dpre && (indeg == nullptr || seg_ptr != nullptr), SAGE_EINVAL,
+               "sage_pool_max_bwd: NULL pointer argument");
+  if (indeg != nullptr) {
+    SAGE_CHECK_HIP(hipMemsetAsync(indeg, 0, static_cast<size_t>(num_sources) * sizeof(int), stream),
+                   "sage_pool_max_bwd: clearing the in-degree workspace");
+    pool_indeg_kernel<<<static_cast<unsigned>(num_targets), kWave, 0, stream>>>(
+        seg_ptr, src, num_targets, num_targets_dev, num_sources, indeg);
+    SAGE_CHECK_LAUNCH("pool_indeg_kernel");
+    // (a 16-byte variant of this kernel measured the same: 142 us against 200 us all-atomic on a
+    // Reddit-shaped batch, where 60 % of the edges end in rows shared by several targets)
+    pool_max_bwd_rows_kernel<<<static_cast<unsigned>(num_targets), kBlock, 0, stream>>>(
+        dagg, ld_dagg, agg, ld_agg, seg_ptr, src, argmax, num_targets, num_targets_dev, num_features,
+        num_sources, indeg, dpre, ld_dpre);
+    SAGE_CHECK_LAUNCH("pool_max_bwd_rows_kernel");
+  } else {
+    pool_max_bwd_kernel<<<static_cast<unsigned>(num_targets), kBlock, 0, stream>>>(
+        dagg, ld_dagg, agg, ld_agg, src, argmax, num_targets, num_targets_dev, num_features, dpre, ld_dpre);
+    SAGE_CHECK_LAUNCH("pool_max_bwd_kernel");
+  }
+  if (dbias != nullptr) {
+    const dim3 grid(static_cast<unsigned>(cdiv(num_features, kBlock)),
+                    static_cast<unsigned>(cdiv(num_targets, kPoolRowsPerBlock)));
+    pool_max_dbias_kernel<<<grid, kBlock, 0, stream>>>(dagg, ld_dagg, agg, ld_agg, num_targets,
+                                                       num_targets_dev, num_features, dbias);
+    SAGE_CHECK_LAUNCH("pool_max_dbias_kernel");
+  }
+  return SAGE_OK;
 }
 
 extern "C" int sage_gather_reduce_bwd(const float* dout, sage_i64 ld_dout, const sage_i64* seg_ptr,

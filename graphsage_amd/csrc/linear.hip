@@ -87,6 +87,14 @@ struct GemmArgs {
   int n2;
   float* out2;
   int64_t ld_out2;
+  // whole-tile epilogues only (one owner per element): a second buffer of out's shape whose
+  // rows < m are handed back zeroed by the same stores (sage_pool_linear_fwd)
+  float* zero2;
+  int64_t ld_zero2;
+  // 1: workgroups that run on one XCD (dispatch order: linear workgroup id modulo 8) take
+  // neighbouring pieces of the problem, so that operand pieces several of them need are fetched
+  // into that XCD's L2 once (SAGE_GEMM_XCD=0 keeps the plain order: A/B switch)
+  int xcd_map;
 };
 
 // ---- global -> register staging of one operand tile ---------------------------------
@@ -829,6 +837,7 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
           if (col < n_lim && row0 + r < m_lim) {
             if (g.rmw_out) v += base[r * ld_out_p];
             base[r * ld_out_p] = v;
+            if (g.zero2 != nullptr) g.zero2[(row0 + r) * g.ld_zero2 + col] = 0.f;
           }
         }
       }
@@ -883,10 +892,21 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
   if (gridDim.x % 8 == 0) lb_ = (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8;
   int64_t it = total * lb_ / gridDim.x;
   int64_t end_ = total * (lb_ + 1) / gridDim.x;
+  int64_t tile_skip = 0;   // K-steps skipped after every tile
   if (g.whole) {   // whole tiles only: the range boundaries are tile boundaries
     const int64_t ntiles = total / S;
     it = ntiles * lb_ / gridDim.x * S;
     end_ = ntiles * (lb_ + 1) / gridDim.x * S;
+    if (g.xcd_map && gridDim.x % 8 == 0) {
+      // the XCD's share of the tiles dealt round-robin to its workgroups: at any time they work
+      // on ~gridDim.x / 8 CONSECUTIVE tiles, i.e. on all column tiles of a few row tiles, whose A
+      // rows (random table rows through a row map: the pool Linear) then come out of L2 for all
+      // but the first of them
+      const unsigned xcd = blockIdx.x % 8, j = blockIdx.x / 8, per = gridDim.x / 8;
+      it = (ntiles * xcd / 8 + j) * S;
+      end_ = ntiles * (xcd + 1) / 8 * S;
+      tile_skip = static_cast<int64_t>(per - 1) * S;
+    }
   }
   const int64_t end = end_;
 
@@ -915,7 +935,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
     const int u0 = static_cast<int>(it - tile * S);
     const int64_t left = end - it;
     const int u1 = left < S - u0 ? u0 + static_cast<int>(left) : S;
-    it += u1 - u0;
+    it += u1 - u0 + tile_skip;
     const int64_t m0 = tile / tiles_n * BM, n0 = tile % tiles_n * BN;
     const int a_lo = u0 < S0 ? u0 : S0, a_hi = u1 < S0 ? u1 : S0;
     const int b_lo = (u0 > S0 ? u0 : S0) - S0, b_hi = (u1 > S0 ? u1 : S0) - S0;
@@ -1015,6 +1035,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
               if (relu) v = fmaxf(v, 0.f);
               if (g.rmw_out) v += base[e * g.ld_out];
               base[e * g.ld_out] = v;
+              if (g.zero2 != nullptr) g.zero2[(row0 + e) * g.ld_zero2 + col] = 0.f;
             }
           }
         }
@@ -1035,10 +1056,24 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   constexpr int BM = 64, BN = 128;
   constexpr int PLANE = BK * kX3DwRowBytes;
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
-  int by = blockIdx.y;
+  unsigned bx = blockIdx.x, by_ = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_map) {
+    // XCD c runs the workgroups with linear id = c (mod 8): give it a CONTIGUOUS range of
+    // (slice, column tile, row tile) triples, i.e. whole split-K slices — every tile of a slice
+    // streams the same rows of both operands, which then cross HBM -> L2 once instead of once
+    // per XCD that holds one of the slice's tiles
+    const unsigned gx = gridDim.x, gy = gridDim.y, W = gx * gy * gridDim.z;
+    const unsigned L = bx + gx * (by_ + gy * bz);
+    const unsigned xcd = L % 8, qn = W / 8, rn = W % 8;
+    const unsigned Lp = xcd * qn + (xcd < rn ? xcd : rn) + L / 8;
+    bx = Lp % gx;
+    by_ = Lp / gx % gy;
+    bz = Lp / (gx * gy);
+  }
+  int by = static_cast<int>(by_);
   const bool prob = g.batched && by >= g.ny0;
   if (prob) by -= g.ny0;
-  const int64_t m0 = static_cast<int64_t>(blockIdx.x) * BM, n0 = static_cast<int64_t>(by) * BN;
+  const int64_t m0 = static_cast<int64_t>(bx) * BM, n0 = static_cast<int64_t>(by) * BN;
   const int64_t m_lim = g.m;
   const int64_t n_lim = prob ? g.n2 : g.n;
   float* const out_p = prob ? g.out2 : g.out;
@@ -1061,7 +1096,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   int k_beg = 0, k_end = k_lim;
   if (g.k_chunk > 0) {
     const int chunk = split_chunk(g.k_chunk, g.k_dev != nullptr, k_lim);
-    k_beg = blockIdx.z * chunk;
+    k_beg = bz * chunk;
     k_end = k_beg + chunk < k_lim ? k_beg + chunk : k_lim;
   }
   if (m0 >= m_lim || k_beg >= k_end) return;   // block-uniform: EXEC stays full for the transposing reads
@@ -1167,6 +1202,11 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
 
 // bf16x3 mode is the default for the large contractions; SAGE_GEMM_X3=0 in the environment
 // (read at every call) keeps them on the exact-fp32 MFMA
+bool xcd_mode() {
+  const char* v = getenv("SAGE_GEMM_XCD");
+  return v == nullptr || v[0] != '0';
+}
+
 bool x3_mode() {
   const char* v = getenv("SAGE_GEMM_X3");
   return v == nullptr || v[0] != '0';
@@ -1420,13 +1460,16 @@ colsum_kernel(const float* __restrict__ dout, int64_t ld, int64_t m, const int64
 
 using namespace sage;
 
-extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sage_i64* rows1,
-                                      int k1, const float* w1, sage_i64 ld_w1, const float* a2,
-                                      sage_i64 ld_a2, const sage_i64* rows2, int k2,
-                                      const float* w2, sage_i64 ld_w2, const float* bias,
-                                      int epilogue, sage_i64 m, const sage_i64* m_dev, int n,
-                                      float* out, sage_i64 ld_out, void* stream_) {
+static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i64* rows1, int k1,
+                                  const float* w1, sage_i64 ld_w1, const float* a2, sage_i64 ld_a2,
+                                  const sage_i64* rows2, int k2, const float* w2, sage_i64 ld_w2,
+                                  const float* bias, int epilogue, sage_i64 m, const sage_i64* m_dev,
+                                  int n, float* out, sage_i64 ld_out, float* zero2, sage_i64 ld_zero2,
+                                  void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  // (zero2 rides on the plain stores of a whole-tile epilogue: bias / relu launches never split K)
+  SAGE_REQUIRE(zero2 == nullptr || ((epilogue & (SAGE_EPI_BIAS | SAGE_EPI_RELU)) && ld_zero2 >= n),
+               SAGE_EINVAL, "sage_pool_linear_fwd: bad companion buffer");
   SAGE_REQUIRE(m >= 0 && n > 0 && k1 > 0 && k2 >= 0 && ld_out >= n, SAGE_EINVAL,
                "sage_linear_concat_fwd: bad shape (m=%lld n=%d k1=%d k2=%d)", (long long)m, n, k1, k2);
   SAGE_REQUIRE(ld_a1 >= k1 && ld_w1 >= k1 && (k2 == 0 || (ld_a2 >= k2 && ld_w2 >= k2)), SAGE_EINVAL,
@@ -1456,6 +1499,8 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
   g.ld_out = ld_out;
   g.bias = bias;
   g.epilogue = epilogue;
+  g.zero2 = zero2;
+  g.ld_zero2 = ld_zero2;
   // Few output tiles (the class-logit layer: M = 512, N = 41): split the contraction over
   // blockIdx.z so that more than M/64 workgroups share the latency-bound K-steps; the partial
   // sums are combined with fp32 atomics into a zeroed output.
@@ -1497,6 +1542,7 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
         zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
         SAGE_CHECK_LAUNCH("zero_rows_kernel");
       }
+      g.xcd_map = xcd_mode() ? 1 : 0;
       gemm_x3_kernel<<<dim3(static_cast<unsigned>(grid_x3)), kThreads, 0, stream>>>(g);
       SAGE_CHECK_LAUNCH("gemm_x3_kernel");
       return SAGE_OK;
@@ -1522,6 +1568,25 @@ extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sag
   }
   if (accum) g.rmw_out = 1;   // out += product: every element has one owner, plain load-add-store
   return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");
+}
+
+extern "C" int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sage_i64* rows1,
+                                      int k1, const float* w1, sage_i64 ld_w1, const float* a2,
+                                      sage_i64 ld_a2, const sage_i64* rows2, int k2,
+                                      const float* w2, sage_i64 ld_w2, const float* bias,
+                                      int epilogue, sage_i64 m, const sage_i64* m_dev, int n,
+                                      float* out, sage_i64 ld_out, void* stream) {
+  return linear_concat_fwd_impl(a1, ld_a1, rows1, k1, w1, ld_w1, a2, ld_a2, rows2, k2, w2, ld_w2, bias,
+                                epilogue, m, m_dev, n, out, ld_out, nullptr, 0, stream);
+}
+
+extern "C" int sage_pool_linear_fwd(const float* x, sage_i64 ld_x, const sage_i64* rows, int k,
+                                    const float* w, sage_i64 ld_w, const float* bias, sage_i64 m,
+                                    const sage_i64* m_dev, int n, float* p, sage_i64 ld_p, float* dpre,
+                                    sage_i64 ld_dpre, void* stream) {
+  SAGE_REQUIRE(bias != nullptr && p != dpre, SAGE_EINVAL, "sage_pool_linear_fwd: NULL bias or dpre aliasing p");
+  return linear_concat_fwd_impl(x, ld_x, rows, k, w, ld_w, nullptr, 0, nullptr, 0, nullptr, 0, bias,
+                                SAGE_EPI_BIAS | SAGE_EPI_RELU, m, m_dev, n, p, ld_p, dpre, ld_dpre, stream);
 }
 
 extern "C" int sage_linear_dinput(const float* dout, sage_i64 ld_dout, const float* w,
@@ -1641,6 +1706,7 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
     }
     const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(cdiv(k, 128)),
                     static_cast<unsigned>(splits));
+    g.xcd_map = xcd_mode() ? 1 : 0;
     gemm_x3_dw_kernel<<<grid, kThreads, 0, stream>>>(g);
     SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel");
     return SAGE_OK;
@@ -1713,6 +1779,7 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
   if (x3_mode() && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && g.seg[1].b.vec == 4 && m >= 64 * BK) {
     const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
                     static_cast<unsigned>(splits));
+    g.xcd_map = xcd_mode() ? 1 : 0;
     gemm_x3_dw_kernel<<<grid, kThreads, 0, stream>>>(g);
     SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel(pair)");
     return SAGE_OK;

@@ -611,6 +611,65 @@ def relu_bwd(dout, out, m=None, m_dev=None, dz=None, clear_dout=False):
     return dz
 
 
+def pool_linear_fwd(x, w, bias, m=None, m_dev=None, rows=None, out=None, dpre=None):
+    """out = relu(x[rows] @ w^T + bias) (reference layers/sage.py:76,202,206); dpre (out's shape):
+    its rows < m come back zeroed from the same launch."""
+    lib = _lib.load()
+    xp, ld_x = _mat(x, "x")
+    wp, ld_w = _mat(w, "w")
+    n, k = w.shape
+    if x.size(1) != k or bias.numel() != n:
+        raise RuntimeError("pool_linear_fwd: x / w / bias shapes differ")
+    if m is None:
+        m = rows.numel() if rows is not None else x.size(0)
+    m = int(m)
+    if rows is None and x.size(0) < m:
+        raise RuntimeError("pool_linear_fwd: x has fewer than m rows")
+    if out is None:
+        out = empty_rows(m, n, x.device)
+    op, ld_o = _mat(out, "out")
+    if out.size(0) < m or out.size(1) != n:
+        raise RuntimeError("pool_linear_fwd: bad output buffer")
+    zp, ld_z = None, 0
+    if dpre is not None:
+        zp, ld_z = _mat(dpre, "dpre")
+        if dpre.size(0) < m or dpre.size(1) != n:
+            raise RuntimeError("pool_linear_fwd: bad dpre buffer")
+    rc = lib.sage_pool_linear_fwd(xp, ld_x, _rows(rows, m, "rows"), k, wp, ld_w, _vec(bias, torch.float32, "bias"),
+                                  m, _count(m_dev, "m_dev"), n, op, ld_o, zp, ld_z, _stream())
+    _lib.check(rc, "sage_pool_linear_fwd")
+    return out
+
+
+def pool_max_bwd(dagg, agg, seg_ptr, src, argmax, num_targets, dpre, dbias=None, num_targets_dev=None,
+                 indeg=None):
+    """dpre[src[argmax[t, f]], f] += dagg[t, f] where agg[t, f] > 0; dbias += the column sums of
+    what was routed (backward of max over relu(pool(x)) rows, reference layers/sage.py:201-207).
+    dpre holds zeros on entry.  indeg: int32 workspace, one entry per row of dpre — rows with a
+    single incoming edge are then written whole instead of added into."""
+    lib = _lib.load()
+    gp, ld_g = _mat(dagg, "dagg")
+    ap, ld_a = _mat(agg, "agg")
+    zp, ld_z = _mat(dpre, "dpre")
+    T, F = int(num_targets), dagg.size(1)
+    if agg.size(1) != F or dpre.size(1) != F or dagg.size(0) < T or agg.size(0) < T or seg_ptr.numel() < T + 1:
+        raise RuntimeError("pool_max_bwd: shape mismatch")
+    if argmax.shape != (T, F) or not argmax.is_contiguous():
+        raise RuntimeError("pool_max_bwd: needs the forward's argmax [T,F]")
+    if dbias is not None and dbias.numel() < F:
+        raise RuntimeError("pool_max_bwd: dbias shorter than the feature count")
+    S = dpre.size(0)
+    if indeg is not None and (indeg.dtype != torch.int32 or indeg.numel() < S or not indeg.is_contiguous()):
+        raise RuntimeError("pool_max_bwd: indeg must be a contiguous int32 tensor with one entry per dpre row")
+    rc = lib.sage_pool_max_bwd(gp, ld_g, ap, ld_a, _vec(seg_ptr, torch.int64, "seg_ptr"),
+                               _vec(src, torch.int64, "src"), _p(argmax, torch.int64, "argmax"),
+                               T, _count(num_targets_dev, "num_targets_dev"), F, zp, ld_z, S,
+                               _p(indeg, torch.int32, "indeg", allow_none=True),
+                               _vec(dbias, torch.float32, "dbias", allow_none=True), _stream())
+    _lib.check(rc, "sage_pool_max_bwd")
+    return dpre
+
+
 def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None, clear_dh=False):
     """Backward of relu(normalize(z)).  clear_dh=True zeroes the consumed rows of dh."""
     lib = _lib.load()

@@ -358,6 +358,36 @@ int sage_relu_bwd(float* dout, sage_i64 ld_dout, const float* out, sage_i64 ld_o
                   const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz, int clear_dout,
                   void* stream);
 
+/* The pool Linear of the pooling aggregators, relu(pool(x_j)) at layers/sage.py:76,202,206, over the
+ * m rows x[rows[r], :] (rows NULL: x[r, :]; m_dev: optional device-side row count):
+ *   p[r, :] = relu(x[rows[r], :] . w^T + bias)        w is [n, k]
+ * and, in the same stores, dpre[r, :] = 0 for r < m when dpre != NULL: dpre is the buffer
+ * sage_pool_max_bwd scatters the pre-activation gradient into later in the step, so the step needs
+ * no fill pass over it.  sage_linear_concat_fwd with SAGE_EPI_BIAS | SAGE_EPI_RELU otherwise. */
+int sage_pool_linear_fwd(const float* x, sage_i64 ld_x, const sage_i64* rows, int k, const float* w,
+                         sage_i64 ld_w, const float* bias, sage_i64 m, const sage_i64* m_dev, int n,
+                         float* p, sage_i64 ld_p, float* dpre, sage_i64 ld_dpre, void* stream);
+
+/* Backward of the max_pool aggregator's reduce AND of the pool Linear's ReLU in one pass
+ * (autograd of x_j = relu(pool(x_j)) -> scatter(..., reduce='max'), layers/sage.py:201-207):
+ *   dpre[src[e], f] += dagg[t, f]   for e = argmax[t, f] >= 0 and agg[t, f] > 0,
+ * agg being the forward's reduce output (agg[t, f] = p[src[e], f], so agg > 0 is the ReLU mask
+ * of the element the gradient is routed to; no pass over p, no dense gradient of p), and
+ *   dbias[f] += the column sums of what was scattered   (dbias NULL: skipped)
+ * — the pool bias gradient.  dpre must hold zeros in rows < num_sources on entry (e.g. from
+ * sage_pool_linear_fwd).  argmax is the [num_targets, num_features] edge-index array
+ * sage_gather_reduce_fwd wrote; seg_ptr / src are that call's segments.
+ * indeg: optional int32[num_sources] workspace.  With it the call first counts the live targets'
+ * edges per source row; a row with ONE incoming edge is then written whole with plain stores by
+ * that edge's target (the routed value or 0) and only rows shared by several targets take fp32
+ * atomics (sums over targets that share an arg-max row are order-dependent in the last bit).
+ * indeg NULL: every routed element is an atomic add (seg_ptr may then be NULL). */
+int sage_pool_max_bwd(const float* dagg, sage_i64 ld_dagg, const float* agg, sage_i64 ld_agg,
+                      const sage_i64* seg_ptr, const sage_i64* src, const sage_i64* argmax,
+                      sage_i64 num_targets, const sage_i64* num_targets_dev, int num_features,
+                      float* dpre, sage_i64 ld_dpre, sage_i64 num_sources, int* indeg, float* dbias,
+                      void* stream);
+
 /* Mean softmax cross-entropy over m rows and its gradient (F.cross_entropy of
  * experiments/fig2a/runners/graphsage_runners.py:43 / nn.CrossEntropyLoss of
  * trainers/node_level_graphsage_trainers.py:41).  labels are gathered through

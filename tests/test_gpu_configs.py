@@ -235,9 +235,28 @@ def test_reddit_shape_pool_engine_step_matches_module_path(reddit, dev, aggregat
         # differs in sign between the paths move in opposite directions (2 lr apart)
         off = (p.data - q.data).abs() > 1e-6 + 1e-4 * q.data.abs()
         assert int(off.sum()) <= 0.01 * off.numel(), (name, int(off.sum()))
-    # the dP buffers were handed back zeroed for the next step's scatter
+    # the scatter's buffers were handed back zeroed: mean's d P by the relu mask pass ...
     for a in engine.act:
-        assert float(a['dP'].abs().max()) == 0.0
+        if 'dP' in a:
+            assert float(a['dP'].abs().max()) == 0.0
+    # ... and max's d pre by the NEXT step's pool Linear: a second step on other seeds (fewer
+    # sampled rows would leave stale rows behind a wrong clear) still agrees with the module path
+    seeds2 = torch.randperm(data.num_nodes, generator=torch.Generator().manual_seed(3))[:B].to(dev)
+    with torch.no_grad():      # same parameters on both sides again (they moved 2 lr apart where a gradient's sign differed)
+        for p, q in zip(model.parameters(), ref_model.parameters()):
+            q.copy_(p)
+    loss2 = engine.step(seeds2, counter=12)
+    st = engine.buf.state.tolist()
+    nn_, ne = st[0], st[1]
+    node, ei = engine.buf.node[:nn_], torch.stack([engine.buf.src[:ne], engine.buf.dst[:ne]])
+    opt.zero_grad()
+    ref_loss2 = F.cross_entropy(ref_model(data.x[node], ei)[:B], data.y[seeds2])
+    ref_loss2.backward()
+    torch.testing.assert_close(loss2.view(()), ref_loss2.detach(), rtol=1e-5, atol=1e-6)
+    for (name, p), q in zip(model.named_parameters(), ref_model.parameters()):
+        got, want = engine.gviews[p], q.grad
+        err = float((got - want).norm() / want.norm().clamp(min=1e-30))
+        assert err < 2e-3, (name, err)
 
 
 @pytest.mark.parametrize("n_in", [25, 5])

@@ -390,6 +390,90 @@ def test_relu_bwd_matches_threshold_backward(dev):
         assert torch.equal(dout[257:], keep[257:])
 
 
+@pytest.mark.parametrize("m,k,n", [(3000, 100, 72), (70000, 602, 602)])
+def test_pool_linear_fwd_clears_its_companion(dev, m, k, n):
+    """sage_pool_linear_fwd = relu(x[rows] W^T + b) (the fp32 kernel at the small shape, the bf16x3
+    whole-tile kernel at the Reddit one) and, in the same stores, zeroed rows < m_dev of a second
+    buffer; rows beyond the device-side count and the padding columns keep what they held."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    N = m + 500
+    x = ops.empty_rows(N, k, dev)
+    x.copy_(torch.randn(N, k, generator=g, device=dev))
+    w = ops.empty_rows(n, k, dev)
+    w.copy_(torch.randn(n, k, generator=g, device=dev) * 0.1)
+    b = torch.randn(n, generator=g, device=dev)
+    rows = torch.randint(0, N, (m,), generator=g, device=dev)
+    live = m - 77
+    count = torch.tensor([live], dtype=torch.int64, device=dev)
+    out = ops.empty_rows(m, n, dev)
+    out.fill_(-3.0)
+    dpre = ops.empty_rows(m, n, dev)
+    dpre.fill_(5.0)
+    ops.pool_linear_fwd(x, w, b, m=m, m_dev=count, rows=rows, out=out, dpre=dpre)
+    want = torch.relu(x[rows[:live]].double() @ w.double().t() + b.double())
+    err = float((out[:live].double() - want).abs().max())
+    assert err < 2e-5 * max(1.0, float(want.abs().max())), err
+    assert float(out[live:].max()) == -3.0 and float(out[live:].min()) == -3.0
+    assert float(dpre[:live].abs().max()) == 0.0
+    assert float(dpre[live:].min()) == 5.0
+    same = ops.linear_concat_fwd(x, w, bias=b, relu=True, m=m, m_dev=count, rows1=rows)
+    assert torch.equal(same[:live], out[:live])        # the entry point it specialises
+
+
+@pytest.mark.parametrize("T,S,F,fan", [(700, 2500, 602, 10), (64, 90, 37, 3), (300, 50, 1100, 25)])
+def test_pool_max_bwd_matches_scatter_then_relu_mask(dev, T, S, F, fan):
+    """sage_pool_max_bwd against the two passes it replaces (arg-max scatter into a dense d P,
+    threshold_backward against P) and against autograd of amax(relu(pre)[src]) per segment;
+    empty segments, targets beyond the device-side count, ties at zero."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    deg = torch.randint(0, fan + 1, (T,), generator=g, device=dev)
+    deg[::17] = 0
+    seg_ptr = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+    seg_ptr[1:] = deg.cumsum(0)
+    E = int(seg_ptr[-1])
+    src = torch.randint(0, S, (E,), generator=g, device=dev)
+    pre = torch.randn(S, F, generator=g, device=dev)
+    P = ops.empty_rows(S, F, dev)
+    P.copy_(pre.relu())
+    live = T - 9
+    count = torch.tensor([live], dtype=torch.int64, device=dev)
+    agg, argmax = ops.gather_reduce_fwd(P, seg_ptr, src, T, 'max', num_targets_dev=count, want_argmax=True)
+    dagg = ops.empty_rows(T, F, dev)
+    dagg.copy_(torch.randn(T, F, generator=g, device=dev))
+    # the two-pass route
+    dP = ops.empty_rows(S, F, dev, zero=True)
+    ops.gather_reduce_bwd(dagg, seg_ptr, src, T, 'max', dP, argmax=argmax, num_targets_dev=count)
+    want = torch.ops.aten.threshold_backward(dP, P, 0.0)
+    scale = float(want.abs().max())
+    for ws in (None, torch.full((S + 5,), 9, dtype=torch.int32, device=dev)):
+        dpre = ops.empty_rows(S, F, dev, zero=True)
+        db = torch.zeros(F + 3, device=dev)
+        ops.pool_max_bwd(dagg, agg, seg_ptr, src, argmax, T, dpre, dbias=db, num_targets_dev=count, indeg=ws)
+        assert float((dpre - want).abs().max()) <= 1e-5 * scale      # atomics: order of the sums only
+        assert float((db[:F] - want.sum(0)).abs().max()) <= 1e-4 * max(1.0, float(want.sum(0).abs().max()))
+        assert float(db[F:].abs().max()) == 0.0
+        if ws is not None:      # the workspace holds the live targets' edge count per source row
+            live_e = int(seg_ptr[live])
+            assert torch.equal(ws[:S].long(), torch.bincount(src[:live_e], minlength=S))
+            assert int(ws[S:].min()) == 9
+    # autograd of the reference's formulation on the live targets
+    pre_ad = pre.double().requires_grad_(True)
+    Pd = pre_ad.relu()
+    tgt = torch.repeat_interleave(torch.arange(T, device=dev), deg)
+    keep = tgt < live
+    out = torch.zeros(T, F, dtype=torch.float64, device=dev).scatter_reduce(
+        0, tgt[keep].unsqueeze(1).expand(-1, F), Pd[src[keep]], 'amax', include_self=False)
+    # ties (several neighbours at exactly 0) have zero gradient either way: relu'(0) = 0
+    (out * dagg.double()).sum().backward()
+    got = dpre.double()
+    ref = pre_ad.grad
+    # amax's autograd splits the gradient evenly among tied maxima; away from zero ties do not
+    # occur with random rows unless the same source appears twice in a segment, where the sum is equal
+    assert float((got.sum(0) - ref.sum(0)).abs().max()) <= 1e-4 * max(1.0, float(ref.sum(0).abs().max()))
+
+
 def test_dweight_device_count_far_below_capacity(dev):
     """Weight gradients whose contraction length is a device-side count well below the capacity
     the grid was sized for (the pooling aggregators: all sampled nodes, capacity 141k, ~81k
