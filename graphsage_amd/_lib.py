@@ -65,6 +65,8 @@ SIGNATURES = {
                                      _P, c_int64, _P]),
     "sage_pool_max_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P, c_int, _P, c_int64,
                                   c_int64, _P, _P, _P]),
+    "sage_pool_mean_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int, _P, c_int64, c_int64,
+                                   _P, _P]),
     "sage_softmax_xent": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, c_int64,
                                   _P]),
     "sage_logits_xent_fused": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P,

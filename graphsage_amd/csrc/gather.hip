@@ -391,6 +391,46 @@ pool_max_bwd_rows_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const 
   }
 }
 
+// mean_pool's counterpart: d agg[t] / deg(t) goes to EVERY source row of the segment, masked by
+// that row's own P > 0 (read here, once per edge, instead of in a pass over all of P and d P).
+__global__ void __launch_bounds__(kBlock)
+pool_mean_bwd_rows_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const float* __restrict__ p,
+                          int64_t ld_p, const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src,
+                          int64_t num_targets, const int64_t* __restrict__ num_targets_dev, int num_features,
+                          int64_t num_sources, const int* __restrict__ indeg, float* __restrict__ dpre,
+                          int64_t ld_dpre) {
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = blockIdx.x;
+  if (t >= nt) return;
+  const int64_t s0 = seg_ptr[t], s1 = seg_ptr[t + 1];
+  if (s1 <= s0) return;
+  const float inv = 1.f / static_cast<float>(s1 - s0);
+  for (int f0 = 0; f0 < num_features; f0 += kPoolCols * kBlock) {
+    float gf[kPoolCols];
+#pragma unroll
+    for (int c = 0; c < kPoolCols; ++c) {
+      const int f = f0 + c * kBlock + threadIdx.x;
+      gf[c] = f < num_features ? dagg[t * ld_dagg + f] * inv : 0.f;
+    }
+    for (int64_t e = s0; e < s1; ++e) {
+      const int64_t s = src[e];                     // workgroup-uniform
+      if (s < 0 || s >= num_sources) continue;
+      float* row = dpre + s * ld_dpre;
+      const float* prow = p + s * ld_p;
+      const bool own = indeg == nullptr ? false : indeg[s] == 1;
+#pragma unroll
+      for (int c = 0; c < kPoolCols; ++c) {
+        const int f = f0 + c * kBlock + threadIdx.x;
+        if (f < num_features) {
+          const float v = prow[f] > 0.f ? gf[c] : 0.f;
+          if (own) row[f] = v;
+          else if (v != 0.f) atomicAdd(row + f, v);
+        }
+      }
+    }
+  }
+}
+
 // The pool bias gradient of the same step: every (t, f) lands in exactly one row of dpre, so the
 // column sums of dpre are the column sums of the masked dagg — 13k target rows instead of 81k
 // source rows (an empty segment has agg = 0, so agg > 0 alone says "routed and unmasked").
@@ -659,6 +699,31 @@ extern "C" int sage_pool_max_bwd(const float* dagg, sage_i64 ld_dagg, const floa
                                                        num_targets_dev, num_features, dbias);
     SAGE_CHECK_LAUNCH("pool_max_dbias_kernel");
   }
+  return SAGE_OK;
+}
+
+extern "C" int sage_pool_mean_bwd(const float* dagg, sage_i64 ld_dagg, const float* p, sage_i64 ld_p,
+                                  const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                                  const sage_i64* num_targets_dev, int num_features, float* dpre,
+                                  sage_i64 ld_dpre, sage_i64 num_sources, int* indeg, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(num_features > 0 && ld_dagg >= num_features && ld_p >= num_features &&
+                   ld_dpre >= num_features && num_targets >= 0 && num_sources >= 0,
+               SAGE_EINVAL, "sage_pool_mean_bwd: bad shape");
+  if (num_targets == 0) return SAGE_OK;
+  SAGE_REQUIRE(dagg && p && seg_ptr && src && dpre && p != dpre, SAGE_EINVAL,
+               "sage_pool_mean_bwd: NULL pointer argument or dpre aliasing p");
+  if (indeg != nullptr) {
+    SAGE_CHECK_HIP(hipMemsetAsync(indeg, 0, static_cast<size_t>(num_sources) * sizeof(int), stream),
+                   "sage_pool_mean_bwd: clearing the in-degree workspace");
+    pool_indeg_kernel<<<static_cast<unsigned>(num_targets), kWave, 0, stream>>>(
+        seg_ptr, src, num_targets, num_targets_dev, num_sources, indeg);
+    SAGE_CHECK_LAUNCH("pool_indeg_kernel");
+  }
+  pool_mean_bwd_rows_kernel<<<static_cast<unsigned>(num_targets), kBlock, 0, stream>>>(
+      dagg, ld_dagg, p, ld_p, seg_ptr, src, num_targets, num_targets_dev, num_features, num_sources, indeg,
+      dpre, ld_dpre);
+  SAGE_CHECK_LAUNCH("pool_mean_bwd_rows_kernel");
   return SAGE_OK;
 }
 

@@ -200,11 +200,10 @@ class SageTrainEngine:
                     s_cap = self.hop_cap[self.L - i]
                     a['s_cap'] = s_cap
                     a['P'] = padded(s_cap, fin)       # relu(pool(x)) per source row
-                    if self.reduce != 'max':          # (max routes dagg straight into dpre, masked by agg > 0)
-                        a['dP'] = padded(s_cap, fin)  # gradient w.r.t. P (zero between steps)
-                    a['dpre'] = padded(s_cap, fin)    # gradient w.r.t. pool(x): dP * [P > 0]
-                    if self.reduce == 'max':          # the batch's edges per source row (sage_pool_max_bwd)
-                        a['indeg'] = torch.zeros(s_cap, dtype=torch.int32, device=dev)
+                    # gradient w.r.t. pool(x), zeroed by the step's pool Linear and filled by the
+                    # masked scatter (sage_pool_max_bwd / sage_pool_mean_bwd: no dense d P)
+                    a['dpre'] = padded(s_cap, fin)
+                    a['indeg'] = torch.zeros(s_cap, dtype=torch.int32, device=dev)   # the batch's edges per source row
                 act.append(a)
             return act
         self.acts = [make_act() for _ in range(nvar)]
@@ -417,10 +416,10 @@ class SageTrainEngine:
     def _pool_forward(self, slot, i, x, node_map):
         """P = relu(x[rows] @ pool.weight^T + pool.bias) over the layer's source rows."""
         a, layer = self.act[i], self.model.layers[i]
-        # max: the same stores hand dpre back zeroed for this step's masked arg-max scatter
+        # the same stores hand dpre back zeroed for this step's masked scatter
         ops.pool_linear_fwd(x, layer.pool.weight, layer.pool.bias, m=a['s_cap'],
                             m_dev=self.n_dev[slot][a['src_hop']], rows=node_map, out=a['P'],
-                            dpre=a['dpre'] if self.reduce == 'max' else None)
+                            dpre=a['dpre'])
 
     def forward_backward(self, slot=0, skip_gather0=False):
         self.last_slot = slot
@@ -583,9 +582,8 @@ class SageTrainEngine:
             lib.linear_dweight(a['dpre'], x_in, m=s_cap, m_dev=s_dev, rows=rows,
                                dw=self.gviews[layer.pool.weight])
         else:
-            lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, a['dP'],
-                                  num_targets_dev=t_dev)
-            lib.relu_bwd(a['dP'], a['P'], m=s_cap, m_dev=s_dev, dz=a['dpre'], clear_dout=True)
+            lib.pool_mean_bwd(a['dagg'], a['P'], buf.seg_ptr, buf.src, t_cap, a['dpre'], num_targets_dev=t_dev,
+                              indeg=a['indeg'])
             lib.linear_dweight(a['dpre'], x_in, m=s_cap, m_dev=s_dev, rows=rows,
                                dw=self.gviews[layer.pool.weight], dbias=self.gviews[layer.pool.bias])
         if i > 0:

@@ -670,6 +670,27 @@ def pool_max_bwd(dagg, agg, seg_ptr, src, argmax, num_targets, dpre, dbias=None,
     return dpre
 
 
+def pool_mean_bwd(dagg, p, seg_ptr, src, num_targets, dpre, num_targets_dev=None, indeg=None):
+    """dpre[src[e], f] += dagg[t, f] / deg(t) where p[src[e], f] > 0, over every edge e of every
+    target t (backward of mean over relu(pool(x)) rows, reference layers/sage.py:201-210).  dpre
+    holds zeros on entry; indeg as in pool_max_bwd."""
+    lib = _lib.load()
+    gp, ld_g = _mat(dagg, "dagg")
+    pp, ld_p = _mat(p, "p")
+    zp, ld_z = _mat(dpre, "dpre")
+    T, F = int(num_targets), dagg.size(1)
+    S = dpre.size(0)
+    if p.size(1) != F or dpre.size(1) != F or dagg.size(0) < T or p.size(0) < S or seg_ptr.numel() < T + 1:
+        raise RuntimeError("pool_mean_bwd: shape mismatch")
+    if indeg is not None and (indeg.dtype != torch.int32 or indeg.numel() < S or not indeg.is_contiguous()):
+        raise RuntimeError("pool_mean_bwd: indeg must be a contiguous int32 tensor with one entry per dpre row")
+    rc = lib.sage_pool_mean_bwd(gp, ld_g, pp, ld_p, _vec(seg_ptr, torch.int64, "seg_ptr"),
+                                _vec(src, torch.int64, "src"), T, _count(num_targets_dev, "num_targets_dev"), F,
+                                zp, ld_z, S, _p(indeg, torch.int32, "indeg", allow_none=True), _stream())
+    _lib.check(rc, "sage_pool_mean_bwd")
+    return dpre
+
+
 def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None, clear_dh=False):
     """Backward of relu(normalize(z)).  clear_dh=True zeroes the consumed rows of dh."""
     lib = _lib.load()

@@ -388,6 +388,17 @@ int sage_pool_max_bwd(const float* dagg, sage_i64 ld_dagg, const float* agg, sag
                       float* dpre, sage_i64 ld_dpre, sage_i64 num_sources, int* indeg, float* dbias,
                       void* stream);
 
+/* mean_pool's counterpart (scatter(..., reduce='mean') over relu(pool(x_j)), layers/sage.py:201-210):
+ *   dpre[src[e], f] += dagg[t, f] / deg(t)   for every edge e of target t with p[src[e], f] > 0,
+ * p being the pool Linear's output (its own sign is the ReLU mask: read once per edge here instead
+ * of a pass over all of p and a dense gradient of p).  dpre holds zeros in rows < num_sources on
+ * entry; indeg as in sage_pool_max_bwd (rows with one incoming edge are written whole, NULL: all
+ * atomics).  The pool bias gradient is the column sums of dpre (sage_linear_dweight's dbias). */
+int sage_pool_mean_bwd(const float* dagg, sage_i64 ld_dagg, const float* p, sage_i64 ld_p,
+                       const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                       const sage_i64* num_targets_dev, int num_features, float* dpre, sage_i64 ld_dpre,
+                       sage_i64 num_sources, int* indeg, void* stream);
+
 /* Mean softmax cross-entropy over m rows and its gradient (F.cross_entropy of
  * experiments/fig2a/runners/graphsage_runners.py:43 / nn.CrossEntropyLoss of
  * trainers/node_level_graphsage_trainers.py:41).  labels are gathered through

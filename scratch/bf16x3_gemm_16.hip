@@ -217,7 +217,13 @@ gemm_bf16x3(const float* __restrict__ A, const float* __restrict__ B, float* __r
   } while (0)
 
 int main() {
-  const int M = 13312, N = 256, K = 1216;      // multiples of the tile: no bounds handling in the loader
+#ifndef MV
+#define MV 13312
+#define NV 256
+#define KV 1216
+#endif
+  const int M = MV, N = NV, K = KV;      // multiples of the tile: no bounds handling in the loader
+                                         // (-DMV=81408 -DNV=640 -DKV=608: the pool Linear's shape)
   std::vector<float> a((size_t)M * K), b((size_t)N * K);
   srand(1);
   for (auto& v : a) v = (rand() % 200001 - 100000) / 100000.f * ((rand() & 7) == 0 ? 37.f : 1.f);

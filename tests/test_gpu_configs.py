@@ -235,12 +235,9 @@ def test_reddit_shape_pool_engine_step_matches_module_path(reddit, dev, aggregat
         # differs in sign between the paths move in opposite directions (2 lr apart)
         off = (p.data - q.data).abs() > 1e-6 + 1e-4 * q.data.abs()
         assert int(off.sum()) <= 0.01 * off.numel(), (name, int(off.sum()))
-    # the scatter's buffers were handed back zeroed: mean's d P by the relu mask pass ...
-    for a in engine.act:
-        if 'dP' in a:
-            assert float(a['dP'].abs().max()) == 0.0
-    # ... and max's d pre by the NEXT step's pool Linear: a second step on other seeds (fewer
-    # sampled rows would leave stale rows behind a wrong clear) still agrees with the module path
+    # the scatter's buffer d pre is handed back zeroed by the NEXT step's pool Linear: a second
+    # step on other seeds (stale rows would show in every pool gradient) still agrees with the
+    # module path
     seeds2 = torch.randperm(data.num_nodes, generator=torch.Generator().manual_seed(3))[:B].to(dev)
     with torch.no_grad():      # same parameters on both sides again (they moved 2 lr apart where a gradient's sign differed)
         for p, q in zip(model.parameters(), ref_model.parameters()):

@@ -474,6 +474,34 @@ def test_pool_max_bwd_matches_scatter_then_relu_mask(dev, T, S, F, fan):
     assert float((got.sum(0) - ref.sum(0)).abs().max()) <= 1e-4 * max(1.0, float(ref.sum(0).abs().max()))
 
 
+@pytest.mark.parametrize("T,S,F,fan", [(700, 2500, 602, 10), (64, 90, 37, 3), (300, 50, 1100, 25)])
+def test_pool_mean_bwd_matches_scatter_then_relu_mask(dev, T, S, F, fan):
+    """sage_pool_mean_bwd against the two passes it replaces (mean scatter into a dense d P,
+    threshold_backward against P), with and without the in-degree workspace; empty segments,
+    targets beyond the device-side count, sources shared by many targets (S = 50)."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(6)
+    deg = torch.randint(0, fan + 1, (T,), generator=g, device=dev)
+    deg[::13] = 0
+    seg_ptr = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+    seg_ptr[1:] = deg.cumsum(0)
+    src = torch.randint(0, S, (int(seg_ptr[-1]),), generator=g, device=dev)
+    P = ops.empty_rows(S, F, dev)
+    P.copy_(torch.randn(S, F, generator=g, device=dev).relu())
+    live = T - 9
+    count = torch.tensor([live], dtype=torch.int64, device=dev)
+    dagg = ops.empty_rows(T, F, dev)
+    dagg.copy_(torch.randn(T, F, generator=g, device=dev))
+    dP = ops.empty_rows(S, F, dev, zero=True)
+    ops.gather_reduce_bwd(dagg, seg_ptr, src, T, 'mean', dP, num_targets_dev=count)
+    want = torch.ops.aten.threshold_backward(dP, P, 0.0)
+    scale = float(want.abs().max())
+    for ws in (None, torch.full((S,), 9, dtype=torch.int32, device=dev)):
+        dpre = ops.empty_rows(S, F, dev, zero=True)
+        ops.pool_mean_bwd(dagg, P, seg_ptr, src, T, dpre, num_targets_dev=count, indeg=ws)
+        assert float((dpre - want).abs().max()) <= 2e-5 * scale      # atomics: order of the sums only
+
+
 def test_dweight_device_count_far_below_capacity(dev):
     """Weight gradients whose contraction length is a device-side count well below the capacity
     the grid was sized for (the pooling aggregators: all sampled nodes, capacity 141k, ~81k
