@@ -86,7 +86,11 @@ x3_fwd_g(const float* __restrict__ A, const float* __restrict__ B, float* __rest
     if (row < BM && grow >= M) grow = M - 1;
     src[i] = (row < BM ? A : B) + grow * (long)K + c4 * 4;
   }
+#ifdef DEPTH3
+  floatx4 vv[3][LPT];     // register set p holds the K-steps = p (mod 3): loads run THREE steps ahead
+#else
   floatx4 vv[2][LPT];     // register set p holds the K-step of parity p (relative to t_beg)
+#endif
   auto issue = [&](auto set_, int step) {
     typedef const floatx4 __attribute__((address_space(1)))* GlobalVec;
 #ifdef KO_LOADS
@@ -98,10 +102,10 @@ x3_fwd_g(const float* __restrict__ A, const float* __restrict__ B, float* __rest
   const unsigned lds0 = (unsigned)(size_t)(lptr_t)lds;
   // the unit's 8 bytes per plane: row * 64 + ((slot ^ f(row)) * 16) + half * 8, slot = c4 >> 1
   const unsigned w_off = lds0 + rowl * 64 + ((((c4 >> 1) ^ (-((rowl & 15) >> 2))) & 3) << 4) + (c4 & 1) * 8;
-  auto store_part = [&](auto stage_, auto lo_, auto hi_) {
-    constexpr int ST = decltype(stage_)::value, LO = decltype(lo_)::value, HI = decltype(hi_)::value;
+  auto store_set = [&](auto stage_, auto set_, auto lo_, auto hi_) {
+    constexpr int ST = decltype(stage_)::value, SET = decltype(set_)::value, LO = decltype(lo_)::value, HI = decltype(hi_)::value;
     const unsigned wb = w_off + ST * STAGE, wb2 = wb + 2 * PLANE;
-    floatx4 (&v)[LPT] = vv[ST];
+    floatx4 (&v)[LPT] = vv[SET];
 #pragma unroll
     for (int i = LO; i < HI; ++i) {
       unsigned h0, m0_, l0, h1, m1, l1;
@@ -119,6 +123,7 @@ x3_fwd_g(const float* __restrict__ A, const float* __restrict__ B, float* __rest
       if (LPT > 5 && i == 5) { wr<5 * 4096>(wb, u32x2{h0, h1}); wr<PLANE + 5 * 4096>(wb, u32x2{m0_, m1}); wr<5 * 4096>(wb2, u32x2{l0, l1}); }
     }
   };
+  auto store_part = [&](auto stage_, auto lo_, auto hi_) { store_set(stage_, stage_, lo_, hi_); };
 
   floatx4 acc[TI][4];
 #pragma unroll
@@ -232,6 +237,106 @@ x3_fwd_g(const float* __restrict__ A, const float* __restrict__ B, float* __rest
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+#ifdef DEPTH3
+  // step t: LDS stage ST = t & 1 holds step t; set SN = (t+1) % 3 holds step t+1 (stored into the
+  // other stage during this step); set SF = t % 3 (its step t is already in LDS) takes step t+3
+  auto step3 = [&](auto stage_, auto sn_, auto sf_, int t) {
+    constexpr int ST = decltype(stage_)::value;
+    using NX = std::integral_constant<int, ST ^ 1>;
+    const unsigned ab = a_off + ST * STAGE, bb = b_off + ST * STAGE;
+    // all A fragments of the step stay (TI x 3), the B fragments of ONE 16-column block at a time
+    // in two rotating sets: 72 fragment registers instead of 96
+    bf16x8 a[TI][3], b[2][3];
+#define RDB(set, j)                                                                               \
+  do {                                                                                            \
+    b[set][0] = rd<(j) * 1024>(bb); b[set][1] = rd<(j) * 1024 + PLANE>(bb);                       \
+    b[set][2] = rd<(j) * 1024 + 2 * PLANE>(bb);                                                   \
+  } while (0)
+#define TIEB(set) "+v"(b[set][0]), "+v"(b[set][1]), "+v"(b[set][2])
+#ifdef KO_MFMA
+#define MFJ(ai, pa, set, pb, j) asm volatile("" : "+v"(acc[ai][j]) : "v"(a[ai][pa]), "v"(b[set][pb]))
+#else
+#define MFJ(ai, pa, set, pb, j) acc[ai][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ai][pa], b[set][pb], acc[ai][j], 0, 0, 0)
+#endif
+#if BMV == 128
+#define MFI(pa, set, pb, j) MFJ(0, pa, set, pb, j); MFJ(1, pa, set, pb, j); MFJ(2, pa, set, pb, j); MFJ(3, pa, set, pb, j)
+#else
+#define MFI(pa, set, pb, j) MFJ(0, pa, set, pb, j); MFJ(1, pa, set, pb, j)
+#endif
+#define PRODJ(set, j)                                                                             \
+  do {                                                                                            \
+    MFI(2, set, 0, j); MFI(0, set, 2, j); MFI(1, set, 1, j); MFI(1, set, 0, j); MFI(0, set, 1, j); \
+    MFI(0, set, 0, j);                                                                            \
+  } while (0)
+    auto products = [&]() {
+      RDA(0, ab, 0);
+      RDA(1, ab, PLANE);
+      RDA(2, ab, 2 * PLANE);
+      RDB(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : AREGS(a, 0), AREGS(a, 1), AREGS(a, 2), TIEB(0));
+      __builtin_amdgcn_sched_barrier(0);
+      RDB(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      PRODJ(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : TIEB(1));
+      __builtin_amdgcn_sched_barrier(0);
+      RDB(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      PRODJ(1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : TIEB(0));
+      __builtin_amdgcn_sched_barrier(0);
+      RDB(1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      PRODJ(0, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" : TIEB(1));
+      __builtin_amdgcn_sched_barrier(0);
+      PRODJ(1, 3);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    issue(sf_, t + 3 < t_end ? t + 3 : t_end - 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < 4) {
+      store_set(NX{}, sn_, I0{}, I6{});
+      __builtin_amdgcn_sched_barrier(0);
+      products();
+    } else {
+      products();
+      store_set(NX{}, sn_, I0{}, I6{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+  };
+  if (t_beg < t_end) {
+    auto cl = [&](int t) { return t < t_end ? t : t_end - 1; };
+    issue(S0{}, t_beg);
+    issue(S1{}, cl(t_beg + 1));
+    issue(S2{}, cl(t_beg + 2));
+    store_set(S0{}, S0{}, I0{}, I6{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int t = t_beg;     // relative step r = t - t_beg: stage r & 1, sets (r+1) % 3 / r % 3
+    for (; t + 5 < t_end; t += 6) {
+      step3(S0{}, S1{}, S0{}, t);
+      step3(S1{}, S2{}, S1{}, t + 1);
+      step3(S0{}, S0{}, S2{}, t + 2);
+      step3(S1{}, S1{}, S0{}, t + 3);
+      step3(S0{}, S2{}, S1{}, t + 4);
+      step3(S1{}, S0{}, S2{}, t + 5);
+    }
+    // remainder (< 6 steps): same rotation, one step at a time
+    if (t < t_end) { step3(S0{}, S1{}, S0{}, t); ++t; }
+    if (t < t_end) { step3(S1{}, S2{}, S1{}, t); ++t; }
+    if (t < t_end) { step3(S0{}, S0{}, S2{}, t); ++t; }
+    if (t < t_end) { step3(S1{}, S1{}, S0{}, t); ++t; }
+    if (t < t_end) { step3(S0{}, S2{}, S1{}, t); ++t; }
+  }
+#else
   if (t_beg < t_end) {
     issue(S0{}, t_beg);
     issue(S1{}, t_beg + 1 < t_end ? t_beg + 1 : t_beg);
@@ -245,6 +350,7 @@ x3_fwd_g(const float* __restrict__ A, const float* __restrict__ B, float* __rest
     }
     if (t < t_end) step(S0{}, t);
   }
+#endif
 
 #pragma unroll
   for (int i = 0; i < TI; ++i)
