@@ -502,6 +502,35 @@ def test_pool_mean_bwd_matches_scatter_then_relu_mask(dev, T, S, F, fan):
         assert float((dpre - want).abs().max()) <= 2e-5 * scale      # atomics: order of the sums only
 
 
+def test_xcd_tile_order_changes_nothing_but_the_order(dev, monkeypatch):
+    """SAGE_GEMM_XCD=0 (plain workgroup -> tile order) against the default XCD-aware order of the
+    bf16x3 kernels: whole-tile forward bitwise equal (every tile has one owner and the same K
+    order), split-K weight gradients equal to summation order."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(12)
+    m, k, n = 40000, 602, 602
+    x = ops.empty_rows(m, k, dev)
+    x.copy_(torch.randn(m, k, generator=g, device=dev))
+    w = ops.empty_rows(n, k, dev)
+    w.copy_(torch.randn(n, k, generator=g, device=dev) * 0.1)
+    b = torch.randn(n, generator=g, device=dev)
+    dout = ops.empty_rows(m, n, dev)
+    dout.copy_(torch.randn(m, n, generator=g, device=dev))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SAGE_GEMM_XCD", mode)
+        out = ops.linear_concat_fwd(x, w, bias=b, relu=True)
+        dw = torch.zeros(n, k, device=dev)
+        ops.linear_dweight(dout, x, dw=dw)
+        torch.cuda.synchronize()
+        res[mode] = (out, dw)
+    assert torch.equal(res["1"][0], res["0"][0])
+    scale = float(res["0"][1].abs().max())
+    assert float((res["1"][1] - res["0"][1]).abs().max()) <= 2e-5 * scale
+    want = dout.double().t() @ x.double()
+    assert float((res["1"][1].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
 def test_dweight_device_count_far_below_capacity(dev):
     """Weight gradients whose contraction length is a device-side count well below the capacity
     the grid was sized for (the pooling aggregators: all sampled nodes, capacity 141k, ~81k
