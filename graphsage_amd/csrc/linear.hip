@@ -869,8 +869,14 @@ __global__ void __launch_bounds__(kThreads, 2) gemm_kernel(GemmArgs g) {
 // or accumulated-into output); 64 x 128 tile, one LDS stage, three resident workgroups per CU,
 // loads two steps ahead.  scratch/bf16x3_gemm.hip is the stand-alone study of this kernel.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-__global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
-  constexpr int BM = 64, BN = 128;
+// BM = 64: three resident workgroups per CU (the stream-K pieces of few-tile shapes, headline);
+// BM = 128 (wave tile 64 x 64): two per CU, a third fewer operand bytes and LDS fragment reads
+// per MFMA — 10 % faster where there are tiles enough to fill the chip several times over
+// (scratch/bf16x3_gemm_16.hip -DBMV=128 at the pool Linear's shape: 462 vs 511 us)
+template <int BM>
+__global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_kernel(GemmArgs g) {
+  constexpr int BN = 128;
+  constexpr int TI = BM / 32;        // 16-row blocks per wave tile
   constexpr int PLANE = (BM + BN) * kX3RowBytes;
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
   int64_t m_lim = g.m;
@@ -912,7 +918,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;     // 16x16x32 operand: row r16, k = 8 kg .. 8 kg + 7
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * 64;
   const int offa = (wm0 + r16) * kX3RowBytes + x3_slot(r16, kg);          // + 16 i rows
   const int offb = (BM + wn0 + r16) * kX3RowBytes + x3_slot(r16, kg);     // + 16 j rows
   typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -948,9 +954,9 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
     const int nsteps = la.range(kb0, ke0, kb1, ke1);
     lb.range(kb0, ke0, kb1, ke1);
 
-    floatx4 acc[2][4];       // the wave's 32 x 64 tile as 2 x 4 blocks of 16 x 16
+    floatx4 acc[TI][4];      // the wave's (BM/2) x 64 tile as TI x 4 blocks of 16 x 16
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -962,11 +968,11 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
     auto mfmas = [&]() {
       // the A fragments stay, the B fragments of one 16-column block at a time (register budget:
       // 168 VGPRs at three workgroups per CU)
-      bf16x8 a[2][3];
+      bf16x8 a[TI][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) a[i][p] = frag(lds + p * PLANE + offa + i * 16 * kX3RowBytes);
+        for (int i = 0; i < TI; ++i) a[i][p] = frag(lds + p * PLANE + offa + i * 16 * kX3RowBytes);
       // (a term, b term) of the six products, smallest first: lo.hi hi.lo mid.mid mid.hi hi.mid hi.hi
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -977,7 +983,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int q = 0; q < 6; ++q)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TI; ++i)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA[q]], b[PB[q]], acc[i][j], 0, 0, 0);
       }
     };
@@ -1014,7 +1020,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_kernel(GemmArgs g) {
     }
     // C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int64_t col = n0 + wn0 + j * 16 + r16;
@@ -1543,7 +1549,13 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
         SAGE_CHECK_LAUNCH("zero_rows_kernel");
       }
       g.xcd_map = xcd_mode() ? 1 : 0;
-      gemm_x3_kernel<<<dim3(static_cast<unsigned>(grid_x3)), kThreads, 0, stream>>>(g);
+      // whole tiles, and enough 128-row ones for several rounds of two workgroups per CU
+      const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
+      if (whole && cdiv(m, 128) * cdiv(n, 128) >= 4ll * slots && !(bm_env && bm_env[0] == '6')) {
+        gemm_x3_kernel<128><<<dim3(static_cast<unsigned>(slots)), kThreads, 0, stream>>>(g);
+      } else {
+        gemm_x3_kernel<64><<<dim3(static_cast<unsigned>(grid_x3)), kThreads, 0, stream>>>(g);
+      }
       SAGE_CHECK_LAUNCH("gemm_x3_kernel");
       return SAGE_OK;
     }
