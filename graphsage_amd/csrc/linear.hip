@@ -1056,10 +1056,15 @@ __global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_kernel(Gem
 // arguments as the fp32 d-weight launch (split-K over blockIdx.z, the two problems of a layer
 // over blockIdx.y, device-side contraction length, fp32 atomics into dw).
 // scratch/bf16x3_dweight.hip is the stand-alone study.
-constexpr int kX3DwRowBytes = 448;   // 192 bf16 columns + 64 B: 112 dwords = 48 (mod 64), so the 4 rows
-                                     // x 16 dwords of a half-wave's transposing read tile the 64 banks
-__global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
-  constexpr int BM = 64, BN = 128;
+// LDS row of one plane: (BM + 128) bf16 columns + 64 B.  448 B = 112 dwords = 48 (mod 64) for BM = 64,
+// 576 B = 144 dwords = 16 (mod 64) for BM = 128: either way the 4 rows x 16 dwords of a half-wave's
+// transposing read tile the 64 banks.  BM = 128 (64 x 64 wave tiles, two workgroups per CU): fewer
+// operand bytes and fragment reads per MFMA, for weight matrices with tiles enough (the pool Linear's).
+template <int BM>
+__global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_dw_kernel(GemmArgs g) {
+  constexpr int BN = 128;
+  constexpr int TI = BM / 32;
+  constexpr int kX3DwRowBytes = (BM + BN) * 2 + 64;
   constexpr int PLANE = BK * kX3DwRowBytes;
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
   unsigned bx = blockIdx.x, by_ = blockIdx.y, bz = blockIdx.z;
@@ -1109,7 +1114,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;     // 16x16x32 operand: column r16, k = 8 kg .. 8 kg + 7
-  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 64;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * 64;
   // transposing read: lane 4q+p of a 16-lane group addresses row (k) q, columns 4p..4p+3 of a
   // 4 x 16 block and receives column (lane & 15) of it, row q in element q.  Group kg reads rows
   // 8 kg + q (and + 4 in a second read) of the 16 columns of block cb.
@@ -1131,9 +1136,9 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   TileLoader<false, BN, 4> lb;
   la.begin(oa, m0, m_lim, k_beg, k_end);
   lb.begin(ob, n0, n_lim, k_beg, k_end);
-  floatx4 acc[2][4];       // the wave's 32 x 64 tile as 2 x 4 blocks of 16 x 16
+  floatx4 acc[TI][4];      // the wave's (BM/2) x 64 tile as TI x 4 blocks of 16 x 16
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -1142,11 +1147,11 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   // v_mfma_f32_16x16x32_bf16, one K-step of 32 per instruction (see gemm_x3_kernel); the A
   // fragments stay, the B fragments of one 16-column block at a time
   auto mfmas = [&]() {
-    bf16x8 a[2][3];
+    bf16x8 a[TI][3];
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i][p] = frag(lds + p * PLANE, wm0 + 16 * i);
+      for (int i = 0; i < TI; ++i) a[i][p] = frag(lds + p * PLANE, wm0 + 16 * i);
     constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1156,7 +1161,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
 #pragma unroll
       for (int qq = 0; qq < 6; ++qq)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TI; ++i)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA[qq]], b[PB[qq]], acc[i][j], 0, 0, 0);
     }
   };
@@ -1193,7 +1198,7 @@ __global__ void __launch_bounds__(kThreads, 3) gemm_x3_dw_kernel(GemmArgs g) {
   if (k0 < k_end) step(S1_{}, S0_{}, k0);
   // C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t col = n0 + wn0 + j * 16 + r16;
@@ -1716,10 +1721,24 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
       SAGE_CHECK_LAUNCH("colsum_kernel");
       g.colsum = nullptr;
     }
-    const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(cdiv(k, 128)),
-                    static_cast<unsigned>(splits));
     g.xcd_map = xcd_mode() ? 1 : 0;
-    gemm_x3_dw_kernel<<<grid, kThreads, 0, stream>>>(g);
+    const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
+    if (n >= 256 && !(bm_env && bm_env[0] == '6')) {
+      // 128 x 128 tiles, two workgroups per CU: one full round of 512
+      const int64_t tiles2 = cdiv(n, 128) * cdiv(k, 128);
+      int64_t sp = 512 / tiles2;
+      if (sp > max_splits) sp = max_splits;
+      if (sp < 1) sp = 1;
+      g.k_chunk = static_cast<int>(cdiv(cdiv(m, sp), BK) * BK);
+      sp = cdiv(m, g.k_chunk);
+      const dim3 grid(static_cast<unsigned>(cdiv(n, 128)), static_cast<unsigned>(cdiv(k, 128)),
+                      static_cast<unsigned>(sp));
+      gemm_x3_dw_kernel<128><<<grid, kThreads, 0, stream>>>(g);
+    } else {
+      const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(cdiv(k, 128)),
+                      static_cast<unsigned>(splits));
+      gemm_x3_dw_kernel<64><<<grid, kThreads, 0, stream>>>(g);
+    }
     SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel");
     return SAGE_OK;
   }
@@ -1789,10 +1808,23 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
   g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
   splits = cdiv(m, g.k_chunk);
   if (x3_mode() && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && g.seg[1].b.vec == 4 && m >= 64 * BK) {
-    const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
-                    static_cast<unsigned>(splits));
     g.xcd_map = xcd_mode() ? 1 : 0;
-    gemm_x3_dw_kernel<<<grid, kThreads, 0, stream>>>(g);
+    const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
+    if (n >= 256 && !(bm_env && bm_env[0] == '6')) {
+      const int64_t tiles2 = cdiv(n, 128) * (cdiv(k1, 128) + cdiv(k2, 128));
+      int64_t sp = 512 / tiles2;
+      if (sp > max_splits) sp = max_splits;
+      if (sp < 1) sp = 1;
+      g.k_chunk = static_cast<int>(cdiv(cdiv(m, sp), BK) * BK);
+      sp = cdiv(m, g.k_chunk);
+      const dim3 grid(static_cast<unsigned>(cdiv(n, 128)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
+                      static_cast<unsigned>(sp));
+      gemm_x3_dw_kernel<128><<<grid, kThreads, 0, stream>>>(g);
+    } else {
+      const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
+                      static_cast<unsigned>(splits));
+      gemm_x3_dw_kernel<64><<<grid, kThreads, 0, stream>>>(g);
+    }
     SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel(pair)");
     return SAGE_OK;
   }
