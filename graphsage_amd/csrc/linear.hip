@@ -1556,7 +1556,7 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
       g.xcd_map = xcd_mode() ? 1 : 0;
       // whole tiles, and enough 128-row ones for several rounds of two workgroups per CU
       const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
-      if (whole && cdiv(m, 128) * cdiv(n, 128) >= 4ll * slots && !(bm_env && bm_env[0] == '6')) {
+      if (whole && cdiv(m, 128) * cdiv(n, 128) >= 2ll * slots && !(bm_env && bm_env[0] == '6')) {
         gemm_x3_kernel<128><<<dim3(static_cast<unsigned>(slots)), kThreads, 0, stream>>>(g);
       } else {
         gemm_x3_kernel<64><<<dim3(static_cast<unsigned>(grid_x3)), kThreads, 0, stream>>>(g);
