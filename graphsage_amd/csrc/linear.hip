@@ -1544,7 +1544,8 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
     const int64_t grid_x3 = slots / 2 * 3;      // three resident workgroups per CU
     // many tiles per workgroup: whole tiles (plain stores, bias / relu epilogue, out += by
     // load-add-store), the uneven last round costs little; few: stream-K pieces with atomics
-    const bool whole = tiles >= 8 * grid_x3 || (!plain && tiles >= 2 * grid_x3);
+    // (a bias / relu epilogue needs whole tiles whatever their number: one owner per element)
+    const bool whole = tiles >= 8 * grid_x3 || !plain;
     if (x3_mode() && (plain || whole) && n > 64 && slots > 0 && vec4 && steps >= 6ll * slots) {
       if (whole) {
         g.whole = 1;
