@@ -232,6 +232,22 @@ struct TileLoader {
   // rows of the contraction tail are zeroed.  Defined after split_bf16x3 below.
   template <int SET>
   __device__ inline void store_x3(int k0, unsigned char* lds, int col0, int row_bytes, int plane_bytes) const;
+
+  // k-major operand: add the rows (< k_end) of the tile requested by issue(k0) into the thread's
+  // column sums — every pass of a thread covers the same 4 columns (kThreads is a multiple of UPR)
+  template <int SET>
+  __device__ inline void colsum_add(int k0, float (&cs)[4]) const {
+    static_assert(!KC && VEC == 4 && kThreads % UPR == 0, "k-major operand in 16-byte vectors");
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+      const bool row_ok = k0 + trow(p) < k_end;
+      const VT x = v[SET][p];
+      cs[0] += row_ok ? x.x : 0.f;
+      cs[1] += row_ok ? x.y : 0.f;
+      cs[2] += row_ok ? x.z : 0.f;
+      cs[3] += row_ok ? x.w : 0.f;
+    }
+  }
 };
 
 // ---- bf16x3 mode (opt-in, SAGE_GEMM_X3=1): an fp32 value as three bf16 terms ------------
@@ -1165,6 +1181,12 @@ __global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_dw_kernel(
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][PA[qq]], b[PB[qq]], acc[i][j], 0, 0, 0);
     }
   };
+  // bias gradient as a by-product (colsum[n] += sum_m dout[m][n], the column sums of the A operand):
+  // the workgroups of the first column tile add the rows they stage anyway, in registers; one
+  // atomic per column and split-K slice at the end (adds to one address serialise at ~65 ns each:
+  // a separate pass over dout with hundreds of row chunks spends its time there)
+  const bool do_cs = g.colsum != nullptr && by == 0 && !prob;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   using S0_ = std::integral_constant<int, 0>;
   using S1_ = std::integral_constant<int, 1>;
   // one step: LDS holds the tile at k0, set HOLD the one at k0 + BK, set FREE takes k0 + 2 BK
@@ -1179,6 +1201,7 @@ __global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_dw_kernel(
     __syncthreads();
     la.template store_x3<HOLD>(k0 + BK, lds, 0, kX3DwRowBytes, PLANE);
     lb.template store_x3<HOLD>(k0 + BK, lds, BM, kX3DwRowBytes, PLANE);
+    if (do_cs) la.template colsum_add<HOLD>(k0 + BK, cs);     // block-uniform; registers only
     __syncthreads();
   };
   la.template issue<0>(k_beg);
@@ -1189,6 +1212,7 @@ __global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_dw_kernel(
   __builtin_amdgcn_sched_barrier(0);
   la.template store_x3<0>(k_beg, lds, 0, kX3DwRowBytes, PLANE);
   lb.template store_x3<0>(k_beg, lds, BM, kX3DwRowBytes, PLANE);
+  if (do_cs) la.template colsum_add<0>(k_beg, cs);
   __syncthreads();
   int k0 = k_beg;
   for (; k0 + BK < k_end; k0 += 2 * BK) {
@@ -1196,6 +1220,23 @@ __global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_dw_kernel(
     step(S0_{}, S1_{}, k0 + BK);
   }
   if (k0 < k_end) step(S1_{}, S0_{}, k0);
+  if (do_cs) {   // (the last step ended with a barrier and nothing reads its LDS image)
+    constexpr int UPR = BM / 4;                 // threads that share a row of the A tile = distinct column groups
+    float* part = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[threadIdx.x * 4 + j] = cs[j];
+    __syncthreads();
+    if (threadIdx.x < UPR) {
+      float tot[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < kThreads / UPR; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tot[j] += part[(r * UPR + threadIdx.x) * 4 + j];
+      const int64_t c0 = m0 + threadIdx.x * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < m_lim) atomicAdd(g.colsum + c0 + j, tot[j]);
+    }
+  }
   // C/D of the 16x16 MFMA: col = lane & 15, row = 4 (lane >> 4) + register
 #pragma unroll
   for (int i = 0; i < TI; ++i)
@@ -1438,32 +1479,6 @@ skinny_dweight_kernel(const float* __restrict__ dout, int64_t ld_dout, SkinnyDwP
     for (int64_t mm = m_beg; mm < m_end; ++mm) sb += dout[mm * ld_dout + n0 + threadIdx.x];
     atomicAdd(dbias + n0 + threadIdx.x, sb);
   }
-}
-
-// dbias[n] += sum over a chunk of rows of dout[m][n]: thread per column, coalesced along n
-__global__ void __launch_bounds__(kThreads)
-colsum_kernel(const float* __restrict__ dout, int64_t ld, int64_t m, const int64_t* __restrict__ m_dev,
-              int n, int m_chunk, float* __restrict__ dbias) {
-  int64_t m_lim = m;
-  if (m_dev != nullptr) {
-    const int64_t v = *m_dev;
-    if (v < m_lim) m_lim = v;
-  }
-  const int col = blockIdx.x * kThreads + threadIdx.x;
-  const int64_t m_beg = static_cast<int64_t>(blockIdx.y) * m_chunk;
-  int64_t m_end = m_beg + m_chunk;
-  if (m_end > m_lim) m_end = m_lim;
-  if (col >= n || m_beg >= m_end) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int64_t r = m_beg;
-  for (; r + 3 < m_end; r += 4) {
-    s0 += dout[r * ld + col];
-    s1 += dout[(r + 1) * ld + col];
-    s2 += dout[(r + 2) * ld + col];
-    s3 += dout[(r + 3) * ld + col];
-  }
-  for (; r < m_end; ++r) s0 += dout[r * ld + col];
-  atomicAdd(dbias + col, (s0 + s1) + (s2 + s3));
 }
 
 }  // namespace
@@ -1715,13 +1730,6 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
   splits = cdiv(m, g.k_chunk);
   if (x3_mode() && k > 64 && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && m >= 64 * BK) {
-    if (dbias != nullptr) {   // the bf16x3 kernel has no column-sum side output
-      const int m_chunk = 256;
-      const dim3 cgrid(static_cast<unsigned>(cdiv(n, kThreads)), static_cast<unsigned>(cdiv(m, m_chunk)));
-      colsum_kernel<<<cgrid, kThreads, 0, stream>>>(dout, ld_dout, m, m_dev, n, m_chunk, dbias);
-      SAGE_CHECK_LAUNCH("colsum_kernel");
-      g.colsum = nullptr;
-    }
     g.xcd_map = xcd_mode() ? 1 : 0;
     const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
     if (n >= 256 && !(bm_env && bm_env[0] == '6')) {
