@@ -30,6 +30,10 @@ __global__ void zero_i64_kernel(int64_t* p, int64_t n) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0;
 }
+__global__ void zero_i32_kernel(int* p, int64_t n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kRowsInFlight = 4;
 
@@ -688,8 +692,10 @@ extern "C" int sage_pool_max_bwd(const float* dagg, sage_i64 ld_dagg, const floa
   SAGE_REQUIRE(dagg && agg && src && argmax && dpre && (indeg == nullptr || seg_ptr != nullptr), SAGE_EINVAL,
                "sage_pool_max_bwd: NULL pointer argument");
   if (indeg != nullptr) {
-    SAGE_CHECK_HIP(hipMemsetAsync(indeg, 0, static_cast<size_t>(num_sources) * sizeof(int), stream),
-                   "sage_pool_max_bwd: clearing the in-degree workspace");
+    if (num_sources > 0) {     // (no edge passes the kernels' source-range check otherwise)
+      zero_i32_kernel<<<static_cast<unsigned>(cdiv(num_sources, kBlock)), kBlock, 0, stream>>>(indeg, num_sources);
+      SAGE_CHECK_LAUNCH("zero_i32_kernel");
+    }
     pool_indeg_kernel<<<static_cast<unsigned>(num_targets), kWave, 0, stream>>>(
         seg_ptr, src, num_targets, num_targets_dev, num_sources, indeg);
     SAGE_CHECK_LAUNCH("pool_indeg_kernel");
@@ -726,8 +732,10 @@ extern "C" int sage_pool_mean_bwd(const float* dagg, sage_i64 ld_dagg, const flo
   SAGE_REQUIRE(dagg && p && seg_ptr && src && dpre && p != dpre, SAGE_EINVAL,
                "sage_pool_mean_bwd: NULL pointer argument or dpre aliasing p");
   if (indeg != nullptr) {
-    SAGE_CHECK_HIP(hipMemsetAsync(indeg, 0, static_cast<size_t>(num_sources) * sizeof(int), stream),
-                   "sage_pool_mean_bwd: clearing the in-degree workspace");
+    if (num_sources > 0) {     // (no edge passes the kernels' source-range check otherwise)
+      zero_i32_kernel<<<static_cast<unsigned>(cdiv(num_sources, kBlock)), kBlock, 0, stream>>>(indeg, num_sources);
+      SAGE_CHECK_LAUNCH("zero_i32_kernel");
+    }
     pool_indeg_kernel<<<static_cast<unsigned>(num_targets), kWave, 0, stream>>>(
         seg_ptr, src, num_targets, num_targets_dev, num_sources, indeg);
     SAGE_CHECK_LAUNCH("pool_indeg_kernel");
