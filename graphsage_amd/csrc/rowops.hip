@@ -276,6 +276,36 @@ logits_xent_fused_kernel(float* __restrict__ z, int64_t ld_z,
   }
 }
 
+// Cross-entropy of m rows with one WAVE PER ROW over as many workgroups as that takes; the row
+// losses go to a caller buffer and mean_reduce_kernel sums them in a fixed order (the
+// single-workgroup kernel above walks 512 rows in 35 us: 32 dependent reductions per wave).
+__global__ void __launch_bounds__(kBlock)
+xent_rows_kernel(const float* __restrict__ logits, int64_t ld_logits, const int64_t* __restrict__ labels,
+                 const int64_t* __restrict__ label_rows, int64_t m, int n, float grad_scale,
+                 float* __restrict__ row_loss, float* __restrict__ dlogits, int64_t ld_dlogits) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (r >= m) return;
+  const int64_t lab = labels[label_rows != nullptr ? label_rows[r] : r];
+  const float* lr = logits + r * ld_logits;
+  float mx = -INFINITY;
+  for (int f = lane; f < n; f += kWave) mx = fmaxf(mx, lr[f]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int f = lane; f < n; f += kWave) se += expf(lr[f] - mx);
+  se = wave_sum(se);
+  const float lse = mx + logf(se);
+  if (lane == 0) row_loss[r] = (lab >= 0 && lab < n) ? lse - lr[lab] : 0.f;
+  if (dlogits != nullptr) {
+    const float scale = grad_scale / static_cast<float>(m);
+    for (int f = lane; f < n; f += kWave) {
+      float p = expf(lr[f] - lse);
+      if (f == lab) p -= 1.f;
+      dlogits[r * ld_dlogits + f] = p * scale;
+    }
+  }
+}
+
 // loss = mean(row_loss[0:m]) — one workgroup, fixed order: bitwise reproducible
 __global__ void __launch_bounds__(kBlock)
 mean_reduce_kernel(const float* __restrict__ v, int64_t m, float* __restrict__ out) {
@@ -470,6 +500,22 @@ extern "C" int sage_softmax_xent(const float* logits, sage_i64 ld_logits, const 
   softmax_xent_kernel<<<1, kXentBlock, 0, stream>>>(logits, ld_logits, labels, label_rows, m, n,
                                                     grad_scale, loss, dlogits, ld_dlogits);
   SAGE_CHECK_LAUNCH("softmax_xent_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_softmax_xent_rows(const float* logits, sage_i64 ld_logits, const sage_i64* labels,
+                                      const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
+                                      float* row_loss, float* loss, float* dlogits, sage_i64 ld_dlogits,
+                                      void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m > 0 && n > 0 && ld_logits >= n && (dlogits == nullptr || ld_dlogits >= n),
+               SAGE_EINVAL, "sage_softmax_xent_rows: bad shape");
+  SAGE_REQUIRE(logits && labels && row_loss && loss, SAGE_EINVAL, "sage_softmax_xent_rows: NULL pointer argument");
+  xent_rows_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+      logits, ld_logits, labels, label_rows, m, n, grad_scale, row_loss, dlogits, ld_dlogits);
+  SAGE_CHECK_LAUNCH("xent_rows_kernel");
+  mean_reduce_kernel<<<1, kBlock, 0, stream>>>(row_loss, m, loss);
+  SAGE_CHECK_LAUNCH("mean_reduce_kernel");
   return SAGE_OK;
 }
 

@@ -514,7 +514,7 @@ class SageTrainEngine:
             lib.unsup_loss(l0['y'], l1['y'], l2['y'], l0['dy'], l1['dy'], l2['dy'], self.row_loss, self.loss, m=B)
         else:
             lib.softmax_xent(l0['y'], self.labels, label_rows=buf.node, m=B, loss=self.loss_sup, dlogits=l0['dy'],
-                             checked=True)
+                             checked=True, row_loss=self.row_loss)     # (unsup_loss reuses row_loss behind it)
             lib.unsup_loss(l0['y'], l1['y'], l2['y'], l0['dy'], l1['dy'], l2['dy'], self.row_loss, self.loss_unsup,
                            m=B)
             _lib.tape_py(lambda: torch.add(self.loss_sup, self.loss_unsup, out=self.loss))

@@ -712,8 +712,9 @@ def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None, clear_dh
 
 
 def softmax_xent(logits, labels, label_rows=None, m=None, grad_scale=1.0, loss=None,
-                 dlogits=None, want_grad=True, checked=False):
-    """Mean cross-entropy + gradient (reference fig2a/runners/graphsage_runners.py:43)."""
+                 dlogits=None, want_grad=True, checked=False, row_loss=None):
+    """Mean cross-entropy + gradient (reference fig2a/runners/graphsage_runners.py:43).
+    row_loss (float32[>= m] scratch): the row-parallel kernel writes the per-row losses there."""
     lib = _lib.load()
     lp, ld = _mat(logits, "logits")
     m = logits.size(0) if m is None else int(m)
@@ -736,6 +737,15 @@ def softmax_xent(logits, labels, label_rows=None, m=None, grad_scale=1.0, loss=N
         gp, ld_g = _mat(dlogits, "dlogits")
         if dlogits.size(0) < m or dlogits.size(1) != n:
             raise RuntimeError("softmax_xent: bad dlogits buffer")
+    if row_loss is not None:      # one wave per row over many workgroups, fixed-order mean
+        if row_loss.numel() < m:
+            raise RuntimeError("softmax_xent: row_loss shorter than m")
+        rc = lib.sage_softmax_xent_rows(lp, ld, _vec(labels, torch.int64, "labels"),
+                                        _vec(label_rows, torch.int64, "label_rows", allow_none=True), m, n,
+                                        float(grad_scale), _vec(row_loss, torch.float32, "row_loss"),
+                                        _p(loss, torch.float32, "loss"), gp, ld_g, _stream())
+        _lib.check(rc, "sage_softmax_xent_rows")
+        return loss, dlogits
     rc = lib.sage_softmax_xent(lp, ld, _vec(labels, torch.int64, "labels"),
                                _vec(label_rows, torch.int64, "label_rows", allow_none=True), m, n,
                                float(grad_scale), _p(loss, torch.float32, "loss"), gp, ld_g,

@@ -502,6 +502,30 @@ def test_pool_mean_bwd_matches_scatter_then_relu_mask(dev, T, S, F, fan):
         assert float((dpre - want).abs().max()) <= 2e-5 * scale      # atomics: order of the sums only
 
 
+@pytest.mark.parametrize("m,n", [(512, 41), (37, 7), (300, 200)])
+def test_softmax_xent_rows_matches_single_workgroup_kernel(dev, m, n):
+    """sage_softmax_xent_rows (wave per row, many workgroups, fixed-order mean) against
+    sage_softmax_xent and F.cross_entropy: loss, gradient, labels gathered through label_rows,
+    an out-of-range label contributing 0."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(21)
+    logits = ops.empty_rows(m, n, dev)
+    logits.copy_(torch.randn(m, n, generator=g, device=dev) * 3)
+    labels_all = torch.randint(0, n, (m + 50,), generator=g, device=dev)
+    rows = torch.randperm(m + 50, generator=g, device=dev)[:m]
+    row_loss = torch.full((m + 3,), -1.0, device=dev)
+    loss_a, d_a = ops.softmax_xent(logits, labels_all, label_rows=rows, m=m, grad_scale=0.5, row_loss=row_loss)
+    loss_b, d_b = ops.softmax_xent(logits, labels_all, label_rows=rows, m=m, grad_scale=0.5)
+    lab = labels_all[rows]
+    want = F.cross_entropy(logits.double(), lab)
+    assert abs(float(loss_a) - float(want)) < 1e-5 * max(1.0, float(want))
+    assert abs(float(loss_a) - float(loss_b)) < 1e-5 * max(1.0, float(want))
+    torch.testing.assert_close(d_a, d_b, rtol=1e-5, atol=1e-8)
+    per_row = F.cross_entropy(logits.double(), lab, reduction="none")
+    torch.testing.assert_close(row_loss[:m].double(), per_row, rtol=1e-5, atol=1e-5)
+    assert float(row_loss[m:].max()) == -1.0
+
+
 def test_xcd_tile_order_changes_nothing_but_the_order(dev, monkeypatch):
     """SAGE_GEMM_XCD=0 (plain workgroup -> tile order) against the default XCD-aware order of the
     bf16x3 kernels: whole-tile forward bitwise equal (every tile has one owner and the same K
