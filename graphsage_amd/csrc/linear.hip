@@ -1559,8 +1559,10 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
     const int64_t grid_x3 = slots / 2 * 3;      // three resident workgroups per CU
     // many tiles per workgroup: whole tiles (plain stores, bias / relu epilogue, out += by
     // load-add-store), the uneven last round costs little; few: stream-K pieces with atomics
-    // (a bias / relu epilogue needs whole tiles whatever their number: one owner per element)
-    const bool whole = tiles >= 8 * grid_x3 || !plain;
+    // (a bias / relu epilogue needs whole tiles whatever their number: one owner per element;
+    // short contractions — F = 100: 8 K-steps per tile — gain nothing from sharing K-steps out:
+    // 4 steps and an atomic epilogue per workgroup took 36 us for 1.3 GFLOP)
+    const bool whole = tiles >= 8 * grid_x3 || !plain || cdiv(k1, BK) + cdiv(k2, BK) <= 12;
     if (x3_mode() && (plain || whole) && n > 64 && slots > 0 && vec4 && steps >= 6ll * slots) {
       if (whole) {
         g.whole = 1;
