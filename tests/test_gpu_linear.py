@@ -526,6 +526,39 @@ def test_softmax_xent_rows_matches_single_workgroup_kernel(dev, m, n):
     assert float(row_loss[m:].max()) == -1.0
 
 
+def test_pool_entry_points_on_empty_and_bad_inputs(dev):
+    """Empty batches are no-ops (the reference's loaders can hand over an empty last shard),
+    malformed arguments are refused with an error instead of a launch."""
+    from graphsage_amd import ops
+    F_ = 24
+    x = ops.empty_rows(10, F_, dev, zero=True)
+    w = ops.empty_rows(F_, F_, dev, zero=True)
+    b = torch.zeros(F_, device=dev)
+    out = ops.empty_rows(10, F_, dev)
+    out.fill_(2.0)
+    dpre = ops.empty_rows(10, F_, dev)
+    dpre.fill_(3.0)
+    ops.pool_linear_fwd(x, w, b, m=0, out=out, dpre=dpre)                 # m = 0: nothing touched
+    assert float(out.min()) == 2.0 and float(dpre.min()) == 3.0
+    seg = torch.zeros(1, dtype=torch.int64, device=dev)
+    src = torch.zeros(0, dtype=torch.int64, device=dev)
+    am = torch.zeros((0, F_), dtype=torch.int64, device=dev)
+    ws = torch.full((10,), 7, dtype=torch.int32, device=dev)
+    ops.pool_max_bwd(out[:0], out[:0], seg, src, am, 0, dpre, dbias=b, indeg=ws)
+    ops.pool_mean_bwd(out[:0], out, seg, src, 0, dpre, indeg=ws)
+    torch.cuda.synchronize()
+    assert float(dpre.min()) == 3.0 and int(ws.min()) == 7 and float(b.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.pool_linear_fwd(x, w, b, m=10, out=out, dpre=out)            # companion aliases the output
+    with pytest.raises(RuntimeError):
+        ops.pool_max_bwd(out, out, torch.zeros(11, dtype=torch.int64, device=dev), src,
+                         torch.zeros((10, F_), dtype=torch.int64, device=dev), 10, dpre,
+                         indeg=torch.zeros(3, dtype=torch.int32, device=dev))      # workspace too short
+    with pytest.raises(RuntimeError):
+        ops.softmax_xent(out, torch.zeros(10, dtype=torch.int64, device=dev), m=10,
+                         row_loss=torch.zeros(4, device=dev))                      # row_loss too short
+
+
 def test_xcd_tile_order_changes_nothing_but_the_order(dev, monkeypatch):
     """SAGE_GEMM_XCD=0 (plain workgroup -> tile order) against the default XCD-aware order of the
     bf16x3 kernels: whole-tile forward bitwise equal (every tile has one owner and the same K
