@@ -1562,7 +1562,14 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
     // (a bias / relu epilogue needs whole tiles whatever their number: one owner per element;
     // short contractions — F = 100: 8 K-steps per tile — gain nothing from sharing K-steps out:
     // 4 steps and an atomic epilogue per workgroup took 36 us for 1.3 GFLOP)
-    const bool whole = tiles >= 8 * grid_x3 || !plain || cdiv(k1, BK) + cdiv(k2, BK) <= 12;
+    // 128-row tiles (two workgroups per CU) pay whenever they come as whole tiles in well-filled
+    // rounds: two rounds and more, or a last round at least 90 % full (the lstm gates: 485 and
+    // 970 tiles on 512 slots; the headline's 208 are not, they stay stream-K pieces of 64 x 128)
+    const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
+    const int64_t t128 = cdiv(m, 128) * cdiv(n, 128);
+    const bool fill128 = slots > 0 && !(bm_env && bm_env[0] == '6') &&
+                         (t128 >= 2ll * slots || t128 * 10 >= cdiv(t128, slots) * slots * 9);
+    const bool whole = tiles >= 8 * grid_x3 || !plain || cdiv(k1, BK) + cdiv(k2, BK) <= 12 || fill128;
     if (x3_mode() && (plain || whole) && n > 64 && slots > 0 && vec4 && steps >= 6ll * slots) {
       if (whole) {
         g.whole = 1;
@@ -1572,9 +1579,7 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
         SAGE_CHECK_LAUNCH("zero_rows_kernel");
       }
       g.xcd_map = xcd_mode() ? 1 : 0;
-      // whole tiles, and enough 128-row ones for several rounds of two workgroups per CU
-      const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
-      if (whole && cdiv(m, 128) * cdiv(n, 128) >= 2ll * slots && !(bm_env && bm_env[0] == '6')) {
+      if (whole && fill128) {
         gemm_x3_kernel<128><<<dim3(static_cast<unsigned>(slots)), kThreads, 0, stream>>>(g);
       } else {
         gemm_x3_kernel<64><<<dim3(static_cast<unsigned>(grid_x3)), kThreads, 0, stream>>>(g);
