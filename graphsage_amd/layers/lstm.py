@@ -85,13 +85,19 @@ class _LstmGatesFn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.empty_rows(x.size(0), fdim, x.device, zero=True)
             if T > 0:
-                tmp = ops.empty_rows(T, fdim, x.device)
+                # d x_flat [T, n_in * ld] in TWO contractions over all slots at once (the padded
+                # W_ih read as [4F, n_in * ld]: its pad columns are zeros), then one scatter per slot;
+                # per-slot contractions are 2 n_in launches of a 16-workgroup grid each (22 us apiece
+                # at T = 512)
+                ld = w_pad.size(2)
+                w_flat = w_pad.view(4 * fdim, n_in * ld)
+                tmp = ops.empty_rows(T, n_in * ld, x.device)
+                (a0, a1), (b0, b1) = _blocks(fdim)
+                ops.linear_dinput(dgates[:, a0:a1], w_flat[a0:a1], m=T, out=tmp)
+                ops.linear_dinput(dgates[:, b0:b1], w_flat[b0:b1], m=T, out=tmp, accumulate=True)
                 unit = torch.arange(T + 1, dtype=torch.int64, device=x.device)
-                for j in range(n_in):
-                    (a0, a1), (b0, b1) = _blocks(fdim)
-                    ops.linear_dinput(dgates[:, a0:a1], w_pad[a0:a1, j, :fdim], m=T, out=tmp)
-                    ops.linear_dinput(dgates[:, b0:b1], w_pad[b0:b1, j, :fdim], m=T, out=tmp, accumulate=True)
-                    ops.gather_reduce_bwd(tmp, unit, slots[j], T, "sum", dx)     # dx[slots[j, t]] += tmp[t]
+                for j in range(n_in):     # dx[slots[j, t]] += d x_flat[t, slot j]
+                    ops.gather_reduce_bwd(tmp[:, j * ld:j * ld + fdim], unit, slots[j], T, "sum", dx)
         return dx, None, dw, dbias
 
 
