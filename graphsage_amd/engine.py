@@ -12,7 +12,13 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
   * layer 0 reads neighbour and root rows straight from the global feature table through the
     batch's node vector — batch.x is never materialised;
   * all gradients live in one flat buffer (one all-reduce under data parallelism, one Adam
-    launch).
+    launch);
+  * the class-logit layer of the supervised mean / sum step is two launches
+    (sage_logit_layer_fwd / _bwd: reduce, both weight products, normalise, cross entropy and
+    their backward for the B seed rows);
+  * the pooling aggregators keep P = relu(pool(x)) per SOURCE row of a layer in a static buffer
+    and route d agg back through the reduce and the ReLU in one edge pass
+    (sage_pool_linear_fwd / sage_pool_max_bwd / sage_pool_mean_bwd).
 """
 import os
 
