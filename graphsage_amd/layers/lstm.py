@@ -19,7 +19,8 @@ above with torch.nn.functional on the CPU, and at the Reddit shape against torch
 Kernels: slot indices (HIP) -> gates = x_flat @ W_ih^T + b_ih + b_hh on the MFMA GEMM -> zero-state
 cell non-linearity (HIP).  x_flat [T, n_in*F] (0.8 GB at the Reddit shape) is never materialised:
 the contraction runs as n_in K-segments of width F, segment j reading the feature rows through
-its own row map slots[j] (two segments per launch, `out +=`).  The forget gate multiplies the
+its own row map slots[j] (two segments per launch, `out +=`); small target sets (the layers above
+layer 0: T = batch size) materialise x_flat and contract over all slots at once.  The forget gate multiplies the
 zero initial cell state, so its quarter of W_ih is neither multiplied nor given a gradient
 (3/4 of the flops); W_hh multiplies the zero hidden state and receives a zero gradient, exactly
 as in the reference's single-step use.
@@ -33,6 +34,52 @@ from .. import ops
 def _blocks(fdim):
     """Row blocks of W_ih (torch order i, f, g, o) that reach the output from a zero state."""
     return ((0, fdim), (2 * fdim, 4 * fdim))
+
+
+_FLAT_BYTES = 256 << 20      # x_flat is materialised up to this size (the layers above layer 0: T = batch size)
+
+
+class _LstmGatesFlatFn(Function):
+    """The same gates for a SMALL target set (T x n_in x F floats within _FLAT_BYTES, F a multiple
+    of 16 so that every slot's columns are 64-byte aligned): x_flat [T, n_in*F] is gathered once and
+    the contraction over all slots is one launch per row block of W_ih — at T = 512 the per-slot
+    K-segment launches are 16-workgroup grids of 11-13 us each, 2 x 26 of them per step."""
+
+    @staticmethod
+    def forward(ctx, x, slots, w_ih, bias):
+        n_in, T = slots.shape
+        fdim = x.size(1)
+        idx = slots.t().reshape(-1)                      # row t*n_in + j = slot j of target t
+        x_flat = x.index_select(0, idx).view(T, n_in * fdim)
+        w = w_ih.detach()
+        gates = bias.unsqueeze(0).expand(T, 4 * fdim).contiguous()
+        for r0, r1 in _blocks(fdim):
+            ops.linear_concat_fwd(x_flat, w[r0:r1], m=T, out=gates[:, r0:r1], accumulate=True)
+        ctx.save_for_backward(x_flat, idx, w)
+        ctx.fdim, ctx.n_rows = fdim, x.size(0)
+        return gates
+
+    @staticmethod
+    def backward(ctx, dgates):
+        x_flat, idx, w = ctx.saved_tensors
+        fdim = ctx.fdim
+        T = x_flat.size(0)
+        dgates = dgates.contiguous()
+        dx = dw = dbias = None
+        if ctx.needs_input_grad[3]:
+            dbias = dgates.sum(0)
+        if ctx.needs_input_grad[2]:
+            dw = torch.zeros_like(w)
+            for r0, r1 in _blocks(fdim):
+                ops.linear_dweight(dgates[:, r0:r1], x_flat, m=T, dw=dw[r0:r1])
+        if ctx.needs_input_grad[0]:
+            (a0, a1), (b0, b1) = _blocks(fdim)
+            tmp = torch.empty_like(x_flat)
+            ops.linear_dinput(dgates[:, a0:a1], w[a0:a1], m=T, out=tmp)
+            ops.linear_dinput(dgates[:, b0:b1], w[b0:b1], m=T, out=tmp, accumulate=True)
+            dx = torch.zeros((ctx.n_rows, fdim), dtype=torch.float32, device=x_flat.device)
+            dx.index_add_(0, idx, tmp.view(-1, fdim))
+        return dx, None, dw, dbias
 
 
 class _LstmGatesFn(Function):
@@ -122,5 +169,7 @@ def lstm_aggregate(layer, x_src, plan, num_targets, node_map=None):
         raise RuntimeError("gradient w.r.t. a node_map'ed feature table is not supported")
     slots, nonempty = ops.segment_slots(plan.seg_ptr, plan.src, num_targets, n_in, node_map=node_map)
     bias = layer.lstm.bias_ih + layer.lstm.bias_hh
-    gates = _LstmGatesFn.apply(x_src, slots, layer.lstm.weight_ih, bias)
+    flat = (node_map is None and fdim % 16 == 0 and x_src.is_contiguous()
+            and 4 * num_targets * n_in * fdim <= _FLAT_BYTES)
+    gates = (_LstmGatesFlatFn if flat else _LstmGatesFn).apply(x_src, slots, layer.lstm.weight_ih, bias)
     return _LstmCell0Fn.apply(gates, nonempty, fdim)

@@ -203,11 +203,13 @@ def test_ppi_shaped_multilabel_step_matches_oracle(dev):
     torch.testing.assert_close(full.cpu(), want, rtol=1e-4, atol=ATOL)
 
 
-def test_lstm_aggregator_matches_oracle(dev):
+@pytest.mark.parametrize("fin", [12, 32])
+def test_lstm_aggregator_matches_oracle(dev, fin):
     """a-7: parity unpinned against the reference (its lstm code is disabled as broken); the
-    kernels are checked against the oracle's well-defined restatement."""
+    kernels are checked against the oracle's well-defined restatement.  fin = 12: the K-segment
+    path through per-slot row maps; fin = 32: the materialised x_flat path of small target sets."""
     from graphsage_amd.layers import SAGE
-    n, e, fin, fout, n_in = 120, 700, 12, 8, 4
+    n, e, fout, n_in = 120, 700, 8, 4
     ei = torch.from_numpy(random_graph(n, e, seed=8, isolated=5))
     g = torch.Generator().manual_seed(0)
     x = torch.randn(n, fin, generator=g)
