@@ -1,4 +1,4 @@
-# same-box A/B of library builds (SAGE_HIP_LIB): old, a = packed residual subtraction only, b = + uniform branches without a memory clobber, new = in-tree
+# same-box A/B of two library builds: scratch/libsage_old.so (SAGE_HIP_LIB) against the in-tree one
 set -e
 run() { timeout -k 10 200 python bench.py --cpu-steps 0 --no-variant --steps 600 "$@" > gpurun_out/vab.txt 2>gpurun_out/vab.err || { tail -5 gpurun_out/vab.err; exit 1; }
 python - <<PY
@@ -8,7 +8,8 @@ print("$LABEL", d["ms_per_step"], d["value"], d["final_loss"], (d["roofline"] or
 PY
 }
 for r in 1 2; do
-for v in old a b; do LABEL=mean_$v SAGE_HIP_LIB=$PWD/scratch/libsage_$v.so run; done
+LABEL=mean_old SAGE_HIP_LIB=$PWD/scratch/libsage_old.so run
 LABEL=mean_new run
 done
-for v in old a b; do LABEL=pool_$v SAGE_HIP_LIB=$PWD/scratch/libsage_$v.so run --aggregator max_pool; done
+LABEL=pool_old SAGE_HIP_LIB=$PWD/scratch/libsage_old.so run --aggregator max_pool
+LABEL=pool_new run --aggregator max_pool

@@ -33,6 +33,9 @@ __global__ void __launch_bounds__(512) k(int mode, float* out, float m) {
   const bool do_mfma = mode == 0 || mode == 3 || ((mode == 2 || mode == 4) && wave < 4);
   const bool do_valu = mode == 1 || mode == 3 || ((mode == 2 || mode == 5) && wave >= 4);
   if (!do_mfma && !do_valu) return;
+#ifdef PRIO      // -DPRIO=n: the MFMA waves of mode 2 raise their issue priority
+  if (mode == 2 && do_mfma) __builtin_amdgcn_s_setprio(PRIO);
+#endif
   for (int it = 0; it < ITERS; ++it) {
     if (do_mfma) mfma_block(acc, a, b);           // 16 MFMAs = 256 matrix-pipe cycles
     if (do_valu) valu_block(v, m);                // 64 VALU ops = 256 issue cycles (wave64 on 16 lanes)
