@@ -20,6 +20,7 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
     and route d agg back through the reduce and the ReLU in one edge pass
     (sage_pool_linear_fwd / sage_pool_max_bwd / sage_pool_mean_bwd).
 """
+import contextlib
 import os
 
 import torch
@@ -248,6 +249,8 @@ class SageTrainEngine:
         # VGPR), and on the gather's stream that wait would delay the gather the main stream needs
         # next; the sampler's result is needed two batches later.
         self.samp = torch.cuda.Stream(device=dev) if self.overlap_gather else self.side
+        self.pool_fork = torch.cuda.Stream(device=dev) if (self.pool and not os.environ.get('SAGE_NO_POOL_FORK')) else None
+        self._forked = False
         self.sampled = [torch.cuda.Event() for _ in range(self.nslots)]     # slot sampled (sampler stream)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
         self.cons_ev = [torch.cuda.Event(), torch.cuda.Event()]   # main stream finished a group
@@ -538,9 +541,6 @@ class SageTrainEngine:
         L, buf = self.L, self.bufs[slot]
         act = self.acts[v]
         lib = ops
-        # (the upper layers' weight gradients are leaves of the dependency chain, but forking
-        # them onto another stream costs more in cross-queue waits than the ~20 us it hides:
-        # measured 0.41 -> 0.45 ms/step on MI355X / ROCm 7.2, so everything stays on one stream)
         for i in range(L - 1, -1, -1):
             a, layer = act[i], self.model.layers[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
@@ -550,11 +550,12 @@ class SageTrainEngine:
             x_in = self.features if i == 0 else act[i - 1]['h']
             rows = self._node_map(slot, v) if i == 0 else None
             agg_i = self._agg0(slot, v) if i == 0 else a['agg']
-            if self.root:
-                lib.linear_dweight2(a['dz'], agg_i, self.gviews[layer.lin_l.weight], x_in,
-                                    self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
-            else:
-                lib.linear_dweight(a['dz'], agg_i, m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
+            with self._leaf(t_cap):
+                if self.root:
+                    lib.linear_dweight2(a['dz'], agg_i, self.gviews[layer.lin_l.weight], x_in,
+                                        self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
+                else:
+                    lib.linear_dweight(a['dz'], agg_i, m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
             if self.pool:
                 self._pool_backward(slot, i, x_in, rows)
             elif fused and i == L - 1:
@@ -569,6 +570,31 @@ class SageTrainEngine:
                     lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       argmax=a.get('argmax'), num_targets_dev=t_dev)
+        if self._forked:      # everything behind the backward (Adam, the all-reduce) sees the forked gradients
+            main = torch.cuda.current_stream()
+            _lib.tape_py(lambda: main.wait_stream(self.pool_fork))
+            self._forked = False
+
+    @contextlib.contextmanager
+    def _leaf(self, rows):
+        """Pooling aggregators: the large weight gradients (MFMA-bound) are leaves of the backward,
+        and the aggregate path that continues beside them (d agg, the edge pass into d pre:
+        memory- and atomic-bound, 0.2 ms at the Reddit shape) is long enough to pay for a fork:
+        1.23-1.25 against 1.26 ms per max_pool step, 1.33 against 1.355 for mean_pool
+        (scratch/pool_fork_ab.sh).  In the mean / sum / max / gcn step the same fork cost more in
+        cross-queue waits than the ~20 us it hid (0.41 -> 0.45 ms in round 1), so there everything
+        stays on one stream."""
+        if self.pool_fork is None or rows < 4096:
+            yield
+            return
+        main = torch.cuda.current_stream()
+        _lib.tape_py(lambda: self.pool_fork.wait_stream(main))
+        torch.cuda.set_stream(self.pool_fork)
+        try:
+            yield
+        finally:
+            torch.cuda.set_stream(main)
+        self._forked = True
 
     def _pool_backward(self, slot, i, x_in, rows):
         """Layer i's aggregate path with a pooling aggregator: d agg -> (through the reduce) d P ->
@@ -583,13 +609,16 @@ class SageTrainEngine:
             lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
         if self.reduce == 'max':
             agg_i = self.agg0[slot] if i == 0 else a['agg']
+            # (the bias gradient = column sums of d pre for max as for mean: the weight-gradient
+            # kernel adds them up from the rows it stages anyway, ~6 us against a 13 us pass of
+            # pool_max_bwd's own over d agg)
             lib.pool_max_bwd(a['dagg'], agg_i, buf.seg_ptr, buf.src, a['argmax'], t_cap, a['dpre'],
-                             dbias=self.gviews[layer.pool.bias], num_targets_dev=t_dev, indeg=a['indeg'])
-            lib.linear_dweight(a['dpre'], x_in, m=s_cap, m_dev=s_dev, rows=rows,
-                               dw=self.gviews[layer.pool.weight])
+                             num_targets_dev=t_dev, indeg=a['indeg'])
         else:
             lib.pool_mean_bwd(a['dagg'], a['P'], buf.seg_ptr, buf.src, t_cap, a['dpre'], num_targets_dev=t_dev,
                               indeg=a['indeg'])
+        # (layer 0's is the last kernel of the backward: nothing left to run beside it)
+        with self._leaf(s_cap if i > 0 else 0):
             lib.linear_dweight(a['dpre'], x_in, m=s_cap, m_dev=s_dev, rows=rows,
                                dw=self.gviews[layer.pool.weight], dbias=self.gviews[layer.pool.bias])
         if i > 0:
@@ -872,6 +901,7 @@ class SageTrainEngine:
             raise RuntimeError("a prefetched batch is pending")
         if self.overlap_gather or self.unsup:
             raise NotImplementedError("overlap_gather / unsup are options of the eager pipeline")
+        self.pool_fork = None      # (the captured step stays on one stream)
         self.flush()
         self.seed_pool = seed_pool.contiguous()
         self.split_gather = split_gather
