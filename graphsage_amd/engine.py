@@ -607,16 +607,20 @@ class SageTrainEngine:
                                m=t_cap, m_dev=t_dev)
         else:
             lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
+        # the in-degree workspace (two short launches) pays for itself on the 13k targets of layer
+        # 0; the B seed rows of the layers above are routed with atomics throughout
+        # (max_pool 1.199 against 1.212 ms per step, mean_pool unchanged; scratch/pool_indeg_ab.sh)
+        indeg = a['indeg'] if (t_cap >= 4096 or os.environ.get('SAGE_POOL_INDEG_ALL')) else None
         if self.reduce == 'max':
             agg_i = self.agg0[slot] if i == 0 else a['agg']
             # (the bias gradient = column sums of d pre for max as for mean: the weight-gradient
             # kernel adds them up from the rows it stages anyway, ~6 us against a 13 us pass of
             # pool_max_bwd's own over d agg)
             lib.pool_max_bwd(a['dagg'], agg_i, buf.seg_ptr, buf.src, a['argmax'], t_cap, a['dpre'],
-                             num_targets_dev=t_dev, indeg=a['indeg'])
+                             num_targets_dev=t_dev, indeg=indeg)
         else:
             lib.pool_mean_bwd(a['dagg'], a['P'], buf.seg_ptr, buf.src, t_cap, a['dpre'], num_targets_dev=t_dev,
-                              indeg=a['indeg'])
+                              indeg=indeg)
         # (layer 0's is the last kernel of the backward: nothing left to run beside it)
         with self._leaf(s_cap if i > 0 else 0):
             lib.linear_dweight(a['dpre'], x_in, m=s_cap, m_dev=s_dev, rows=rows,
