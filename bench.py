@@ -477,6 +477,7 @@ def main():
             rec = bracket_contractions(ops)
             pe = make_engine(copy.deepcopy(model), False)
             pe.use_tapes = False
+            pe.pool_fork = None       # every contraction alone on the chip: its own duration
             n_probe = max(1, min(20, args.steps))
             for s_ in range(3):
                 pe.step(seeds_of(s_), counter_of(s_))
@@ -487,7 +488,8 @@ def main():
             torch.cuda.synchronize()
             rec["on"] = False
             roofline = mfma_roofline(rec, n_probe, gemm_mode)
-            roofline["schedule"] = f"separate run of {n_probe} steps without call tapes"
+            roofline["schedule"] = (f"separate run of {n_probe} steps on one stream without call tapes "
+                                    "(the headline run forks the large weight gradients beside the aggregate path)")
             del pe
         if probe:
             src = probe_res if probe_res is not None else res
