@@ -536,6 +536,10 @@ class SageTrainEngine:
             _lib.tape_py(self.grad.zero_)
         for v in range(3 if self.unsup else 1):
             self._backward_layers(slot, v, fused)
+        if self._forked:      # everything behind the backward (Adam, the all-reduce) sees the forked gradients
+            main = torch.cuda.current_stream()
+            _lib.tape_py(lambda: main.wait_stream(self.pool_fork))
+            self._forked = False
 
     def _backward_layers(self, slot, v, fused=False):
         L, buf = self.L, self.bufs[slot]
@@ -570,11 +574,6 @@ class SageTrainEngine:
                     lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       argmax=a.get('argmax'), num_targets_dev=t_dev)
-        if self._forked:      # everything behind the backward (Adam, the all-reduce) sees the forked gradients
-            main = torch.cuda.current_stream()
-            _lib.tape_py(lambda: main.wait_stream(self.pool_fork))
-            self._forked = False
-
     @contextlib.contextmanager
     def _leaf(self, rows):
         """Pooling aggregators: the large weight gradients (MFMA-bound) are leaves of the backward,
