@@ -1,4 +1,5 @@
 # same-box A/B: weight gradients of the three variants of the unsup / trainer step forked (SAGE_UNSUP_FORK=1) or not
+# (the switch existed for this measurement only: engine.py read SAGE_UNSUP_FORK when it created its leaf stream; removed after the A/B)
 set -e
 run() { timeout -k 10 280 python bench.py --cpu-steps 0 --no-variant --no-probe --steps 300 "$@" > gpurun_out/uf.txt 2>gpurun_out/uf.err || { tail -5 gpurun_out/uf.err; exit 1; }
 python - <<PY
