@@ -60,6 +60,7 @@ SIGNATURES = {
                                      _P, c_int, _P]),
     "sage_l2norm_relu_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int64, _P, c_int,
                                      _P, c_int64, c_int, _P]),
+    "sage_l2norm_relu_bwd_z": (c_int, [_P, c_int64, _P, c_int64, c_int, c_int64, _P, c_int, _P, c_int64, c_int, _P]),
     "sage_relu_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int, _P, c_int64, c_int, _P]),
     "sage_pool_linear_fwd": (c_int, [_P, c_int64, _P, c_int, _P, c_int64, _P, c_int64, _P, c_int, _P, c_int64,
                                      _P, c_int64, _P]),
@@ -73,7 +74,7 @@ SIGNATURES = {
     "sage_logits_xent_fused": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P,
                                        _P, c_int64, _P, _P, c_int, _P]),
     "sage_logit_layer_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
-                                     _P, _P, c_float, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P]),
+                                     _P, _P, c_float, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
     "sage_logit_layer_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
                                      _P, c_int64, _P, _P, _P]),
     "sage_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,

@@ -15,6 +15,10 @@
 // The weight gradients stay with sage_linear_dweight2 (they need agg, which the forward keeps).
 #include "common.h"
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 namespace sage {
 namespace {
 
@@ -99,7 +103,11 @@ struct WeightStage {
 };
 
 // NV = H / 256 (a lane holds NV float4 of a row: columns 4 (lane + 64 v) ..)
-template <int NV, bool FULL>      // FULL: h == 256 NV, no lane is ever out of the row
+// PRE: hrows holds the previous layer's PRE-activation rows z; a row becomes relu(z / max(|z|, eps))
+// in registers on its way in (one more butterfly per row, 16 rows at a time), so the previous
+// layer's normalise pass — 54 MB and a launch — is not run at all; the seeds' own activations
+// are written to h_root for the root term's weight gradient.
+template <int NV, bool FULL, bool PRE>      // FULL: h == 256 NV, no lane is ever out of the row
 __global__ void __launch_bounds__(kLogitBlock)
 logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
                  const int64_t* __restrict__ src, int64_t m, int h, int mean,
@@ -107,7 +115,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
                  int n, const int64_t* __restrict__ labels, const int64_t* __restrict__ label_rows,
                  float grad_scale, float* __restrict__ agg, int64_t ld_agg, float* __restrict__ y, int64_t ld_y,
                  float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
-                 float* __restrict__ row_loss) {
+                 float* __restrict__ row_loss, float* __restrict__ h_root, int64_t ld_h_root) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kLogitWaves + threadIdx.x / kWave;
@@ -115,6 +123,24 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   const int nq = h / 4;         // float4 per row
   constexpr int kRowsInFlight = kRowRegs / NV;
   auto in_row = [&](int v) { return FULL || lane + kWave * v < nq; };
+  auto sumsq = [&](const float4 (&r)[NV]) {       // this lane's share of |row|^2
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (in_row(v)) q += r[v].x * r[v].x + r[v].y * r[v].y + r[v].z * r[v].z + r[v].w * r[v].w;
+    }
+    return q;
+  };
+  auto activate = [&](float4 (&r)[NV], float ss) {      // relu(z / max(|z|, eps)), ss = |z|^2 over the wave
+    const float denom = fmaxf(sqrtf(ss), kNormEps);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      r[v].x = fmaxf(r[v].x / denom, 0.f);
+      r[v].y = fmaxf(r[v].y / denom, 0.f);
+      r[v].z = fmaxf(r[v].z / denom, 0.f);
+      r[v].w = fmaxf(r[v].w / denom, 0.f);
+    }
+  };
 
   LOGIT_STAMP(0, 0);
   float4 acc[NV], root[NV];
@@ -140,6 +166,16 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   const int64_t lab = labels[lab_row];                 // needs lab_row
   LOGIT_STAMP(0, 1);
   bool staged = false;
+  if constexpr (PRE) {
+    activate(root, wave_sum(sumsq(root)));
+    if (live && h_root != nullptr) {
+      float4* hp = reinterpret_cast<float4*>(h_root + t * ld_h_root);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        if (in_row(v)) hp[lane + kWave * v] = root[v];
+      }
+    }
+  }
   if (live) {
     for (int64_t base = 0; base < len; base += kWave) {
       const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
@@ -163,6 +199,20 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
         if (!staged) {       // (first round of rows requested: now the weights, which arrived before them)
           st.store(wlds, 0, n, h);
           staged = true;
+        }
+        if constexpr (PRE) {
+          float ss[kRowsInFlight];
+#pragma unroll
+          for (int r = 0; r < kRowsInFlight; ++r) ss[r] = r0 + r < chunk ? sumsq(x[r]) : 0.f;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) {      // the rows' butterflies side by side
+#pragma unroll
+            for (int r = 0; r < kRowsInFlight; ++r) ss[r] += __shfl_xor(ss[r], o);
+          }
+#pragma unroll
+          for (int r = 0; r < kRowsInFlight; ++r) {
+            if (r0 + r < chunk) activate(x[r], ss[r]);
+          }
         }
 #pragma unroll
         for (int r = 0; r < kRowsInFlight; ++r) {
@@ -387,18 +437,22 @@ int check_common(const char* who, sage_i64 m, int h, int n, int reduce, const fl
 
 template <typename K>
 int allow_lds(K kernel, size_t bytes, const char* who) {
-  // above 64 KB of dynamic LDS a kernel has to opt in, once per device (the attribute is kept
-  // at the device's maximum, so the size of a later call never exceeds it)
-  static bool done[64] = {};
+  // above 64 KB of dynamic LDS a kernel has to opt in, once per kernel and device (the attribute
+  // is kept at the device's maximum, so the size of a later call never exceeds it).  Keyed by
+  // the kernel's ADDRESS: every instantiation of one kernel template has the same type K.
+  static std::mutex mu;
+  static std::vector<std::pair<const void*, int>> done;
   if (bytes <= 64 * 1024) return SAGE_OK;
   int dev = 0;
-  SAGE_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64, SAGE_ELAUNCH, "%s: cannot query the device", who);
-  if (!done[dev]) {
-    SAGE_REQUIRE(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024) == hipSuccess,
-                 SAGE_ELAUNCH, "%s: cannot raise the dynamic LDS limit", who);
-    done[dev] = true;
+  SAGE_REQUIRE(hipGetDevice(&dev) == hipSuccess && dev >= 0, SAGE_ELAUNCH, "%s: cannot query the device", who);
+  const std::pair<const void*, int> key(reinterpret_cast<const void*>(kernel), dev);
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto& d : done) {
+    if (d == key) return SAGE_OK;
   }
+  SAGE_REQUIRE(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+               SAGE_ELAUNCH, "%s: cannot raise the dynamic LDS limit", who);
+  done.push_back(key);
   return SAGE_OK;
 }
 
@@ -412,7 +466,7 @@ extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sa
                                     const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
                                     const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
                                     float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
-                                    float* row_loss, void* stream_) {
+                                    float* row_loss, float* h_root, sage_i64 ld_h_root, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   size_t lds = 0;
   const int rc = check_common("sage_logit_layer_fwd", m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
@@ -422,15 +476,23 @@ extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sa
   SAGE_REQUIRE(ld_h >= h && ld_h % 4 == 0 && vec16(h_rows) && ld_agg >= h && ld_agg % 4 == 0 && vec16(agg) && ld_dz >= n &&
                    (y == nullptr || ld_y >= n),
                SAGE_EINVAL, "sage_logit_layer_fwd: rows of h / agg must be 16-byte aligned, ld_dz / ld_y >= n");
+  SAGE_REQUIRE(h_root == nullptr || (ld_h_root >= h && ld_h_root % 4 == 0 && vec16(h_root) && h_root != h_rows), SAGE_EINVAL,
+               "sage_logit_layer_fwd: rows of h_root must be 16-byte aligned and at least h wide, and not alias h_rows");
+  const bool pre = h_root != nullptr;
   const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
   const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
+#define SAGE_LOGIT_FWD_P(NV, FULL, PRE)                                                                         \
+  do {                                                                                                      \
+    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE>, lds, "sage_logit_layer_fwd");                \
+    if (rc2 != SAGE_OK) return rc2;                                                                         \
+    logit_fwd_kernel<NV, FULL, PRE><<<grid, kLogitBlock, lds, stream>>>(                                    \
+        h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, \
+        ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root);                                            \
+  } while (0)
 #define SAGE_LOGIT_FWD(NV, FULL)                                                                                \
   do {                                                                                                      \
-    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL>, lds, "sage_logit_layer_fwd");                     \
-    if (rc2 != SAGE_OK) return rc2;                                                                         \
-    logit_fwd_kernel<NV, FULL><<<grid, kLogitBlock, lds, stream>>>(h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, \
-                                                                   w_r, ld_wr, n, labels, label_rows, grad_scale, agg, \
-                                                                   ld_agg, y, ld_y, inv_norm, dz, ld_dz, row_loss); \
+    if (pre) SAGE_LOGIT_FWD_P(NV, FULL, true);                                                              \
+    else SAGE_LOGIT_FWD_P(NV, FULL, false);                                                                 \
   } while (0)
   const int nv = (h / 4 + kWave - 1) / kWave;
   const bool full = h == nv * 4 * kWave;
@@ -440,6 +502,7 @@ extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sa
   else if (nv == 2) SAGE_LOGIT_FWD(2, false);
   else SAGE_LOGIT_FWD(4, false);
 #undef SAGE_LOGIT_FWD
+#undef SAGE_LOGIT_FWD_P
   SAGE_CHECK_LAUNCH("logit_fwd_kernel");
   return SAGE_OK;
 }

@@ -142,6 +142,65 @@ l2norm_relu_bwd_kernel(float* __restrict__ dh, int64_t ld_dh, const float* __res
   }
 }
 
+// The same backward from the PRE-normalisation rows z (no y / inv_norm kept by a forward pass:
+// the class-logit kernel normalises the rows it gathers on the fly, logit.hip): one wave per
+// row, the row of z and of dh held in registers across both reductions (|z|^2, then <y, g>);
+// z is handed back zeroed, like dh, for the producers that add into it.
+template <int NV>      // float4 per lane: n <= 256 NV
+__global__ void __launch_bounds__(kBlock)
+l2norm_relu_bwd_z_kernel(float* __restrict__ dh, int64_t ld_dh, float* __restrict__ z, int64_t ld_z,
+                         int relu_mask, int64_t m, const int64_t* __restrict__ m_dev, int n,
+                         float* __restrict__ dz, int64_t ld_dz, int clear_dh) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t rows = dev_count(m_dev, m);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (r >= rows) return;
+  const int nq = n / 4;
+  float4* zr = reinterpret_cast<float4*>(z + r * ld_z);
+  float4* gr = reinterpret_cast<float4*>(dh + r * ld_dh);
+  float4* or_ = reinterpret_cast<float4*>(dz + r * ld_dz);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 zv[NV], g[NV];
+  float ss = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int q = lane + kWave * v;
+    zv[v] = g[v] = zero4;
+    if (q < nq) {
+      zv[v] = zr[q];
+      g[v] = gr[q];
+    }
+    ss += zv[v].x * zv[v].x + zv[v].y * zv[v].y + zv[v].z * zv[v].z + zv[v].w * zv[v].w;
+  }
+  ss = wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), kNormEps);
+  const float inv = 1.f / denom;
+  const bool clamped = inv >= 1.f / kNormEps;  // ||z|| <= eps: the clamp's gradient is zero
+  float dot = 0.f;
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    zv[v].x /= denom; zv[v].y /= denom; zv[v].z /= denom; zv[v].w /= denom;      // y, as the forward pass writes it
+    if (relu_mask) {
+      if (!(zv[v].x > 0.f)) g[v].x = 0.f;
+      if (!(zv[v].y > 0.f)) g[v].y = 0.f;
+      if (!(zv[v].z > 0.f)) g[v].z = 0.f;
+      if (!(zv[v].w > 0.f)) g[v].w = 0.f;
+    }
+    dot += zv[v].x * g[v].x + zv[v].y * g[v].y + zv[v].z * g[v].z + zv[v].w * g[v].w;
+  }
+  dot = clamped ? 0.f : wave_sum(dot);
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const int q = lane + kWave * v;
+    if (q < nq) {
+      or_[q] = make_float4((g[v].x - zv[v].x * dot) * inv, (g[v].y - zv[v].y * dot) * inv,
+                           (g[v].z - zv[v].z * dot) * inv, (g[v].w - zv[v].w * dot) * inv);
+      zr[q] = zero4;
+      if (clear_dh) gr[q] = zero4;
+    }
+  }
+}
+
 // One workgroup of 16 waves walks all rows; per-wave partial losses are combined in wave
 // order, so the loss is bitwise reproducible.
 constexpr int kXentBlock = 1024;
@@ -461,6 +520,30 @@ extern "C" int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, s
         dh, ld_dh, y, ld_y, inv_norm, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
   }
   SAGE_CHECK_LAUNCH("l2norm_relu_bwd_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_l2norm_relu_bwd_z(float* dh, sage_i64 ld_dh, float* z, sage_i64 ld_z, int relu_mask,
+                                      sage_i64 m, const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
+                                      int clear_dh, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m >= 0 && n > 0 && ld_dh >= n && ld_z >= n && ld_dz >= n, SAGE_EINVAL,
+               "sage_l2norm_relu_bwd_z: bad shape");
+  if (m == 0) return SAGE_OK;
+  SAGE_REQUIRE(dh && z && dz && dz != z && dh != z, SAGE_EINVAL,
+               "sage_l2norm_relu_bwd_z: NULL pointer argument or dz / dh aliasing z");
+  SAGE_REQUIRE(n % 4 == 0 && n <= 1024 && ld_dh % 4 == 0 && ld_z % 4 == 0 && ld_dz % 4 == 0 && vec16(dh) && vec16(z) &&
+                   vec16(dz),
+               SAGE_ELIMIT, "sage_l2norm_relu_bwd_z: needs 16-byte aligned rows of at most 1024 floats, a multiple of 4");
+  const unsigned grid = static_cast<unsigned>(cdiv(m, kWavesPerBlock));
+  if (n <= 256) {
+    l2norm_relu_bwd_z_kernel<1><<<grid, kBlock, 0, stream>>>(dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
+  } else if (n <= 512) {
+    l2norm_relu_bwd_z_kernel<2><<<grid, kBlock, 0, stream>>>(dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
+  } else {
+    l2norm_relu_bwd_z_kernel<4><<<grid, kBlock, 0, stream>>>(dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
+  }
+  SAGE_CHECK_LAUNCH("l2norm_relu_bwd_z_kernel");
   return SAGE_OK;
 }
 

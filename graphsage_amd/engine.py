@@ -114,6 +114,8 @@ class SageTrainEngine:
         self.fused_logit = (not os.environ.get('SAGE_NO_FUSED_LOGIT') and not unsup and not self.pool
                             and self.root and self.reduce in ('mean', 'sum') and len(model.layers) >= 2
                             and ops.logit_layer_supported(last_w.size(1), last_w.size(0)))
+        # ... and reads the hidden layer's PRE-activation rows (SAGE_NO_PRENORM=1: normalise pass kept)
+        self.prenorm = self.fused_logit and not os.environ.get('SAGE_NO_PRENORM')
         self.features, self.labels = features, labels
         self.B = int(batch_size)
         self.L = len(model.layers)
@@ -457,8 +459,10 @@ class SageTrainEngine:
     def _agg0(self, slot, v):
         return self.agg0[slot] if v == 0 else self.acts[v][0]['agg']
 
-    def _forward_layers(self, slot, v, skip_gather0, upto=None):
-        """Layers of variant v up to the un-normalised logits z (or only the first `upto`)."""
+    def _forward_layers(self, slot, v, skip_gather0, upto=None, raw_last=False):
+        """Layers of variant v up to the un-normalised logits z (or only the first `upto`;
+        raw_last: the last of those is left as its pre-activation rows z — the fused class-logit
+        kernel normalises what it reads)."""
         L, buf = self.L, self.bufs[slot]
         act = self.acts[v]
         x, node_map = self.features, self._node_map(slot, v)
@@ -489,7 +493,7 @@ class SageTrainEngine:
                                   layer.lin_r.weight if self.root else None, m=t_cap,
                                   m_dev=t_dev, rows2=node_map if self.root else None, out=a['z'],
                                   accumulate=(i < L - 1 or not self.unsup))
-            if i < L - 1:
+            if i < L - 1 and not (raw_last and i == upto - 1):
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'],
                                     clear_z=True)
             x, node_map = a.get('h'), None
@@ -498,11 +502,15 @@ class SageTrainEngine:
         buf, lib, B = self.bufs[slot], ops, self.B
         if fused:
             # (training step only: the loss mean then comes out of the backward launch)
-            self._forward_layers(slot, 0, skip_gather0, upto=self.L - 1)
-            last, layer = self.act[-1], self.model.layers[-1]
-            lib.logit_layer_fwd(self.act[-2]['h'], buf.seg_ptr, buf.src, B, self.reduce, layer.lin_l.weight,
-                                layer.lin_r.weight, self.labels, buf.node, last['agg'], last['y'], last['inv'],
-                                last['dz'], self.row_loss)
+            self._forward_layers(slot, 0, skip_gather0, upto=self.L - 1, raw_last=self.prenorm)
+            last, layer, prev = self.act[-1], self.model.layers[-1], self.act[-2]
+            # prenorm: no normalise pass over the hidden layer (54 MB and a launch) — the kernel
+            # takes the ~11 rows per seed it reads through relu(normalize(.)) in registers and
+            # leaves the seeds' own activations in h for the root term's weight gradient; the
+            # backward works from z as well (sage_l2norm_relu_bwd_z) and hands it back zeroed
+            lib.logit_layer_fwd(prev['z'] if self.prenorm else prev['h'], buf.seg_ptr, buf.src, B, self.reduce,
+                                layer.lin_l.weight, layer.lin_r.weight, self.labels, buf.node, last['agg'], last['y'],
+                                last['inv'], last['dz'], self.row_loss, h_root=prev['h'] if self.prenorm else None)
             return
         if not self.unsup:
             self._forward_layers(slot, 0, skip_gather0)
@@ -549,8 +557,11 @@ class SageTrainEngine:
             a, layer = act[i], self.model.layers[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
             if i < L - 1:   # g = gradient w.r.t. relu(normalize(z)), left in dh by layer i+1
-                lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'],
-                                    clear_dh=True)   # dh is zero again for the next step's scatter-add
+                if fused and self.prenorm and i == L - 2:
+                    lib.l2norm_relu_bwd_z(a['dh'], a['z'], True, m=t_cap, m_dev=t_dev, dz=a['dz'], clear_dh=True)
+                else:
+                    lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'],
+                                        clear_dh=True)   # dh is zero again for the next step's scatter-add
             x_in = self.features if i == 0 else act[i - 1]['h']
             rows = self._node_map(slot, v) if i == 0 else None
             agg_i = self._agg0(slot, v) if i == 0 else a['agg']

@@ -711,6 +711,26 @@ def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None, clear_dh
     return dz
 
 
+def l2norm_relu_bwd_z(dh, z, relu, m=None, m_dev=None, dz=None, clear_dh=False):
+    """Backward of relu(normalize(z)) from the pre-normalisation rows z themselves (no y /
+    inv_norm kept by a forward pass: logit_layer_fwd(h_root=...)).  z is handed back zeroed;
+    clear_dh=True zeroes the consumed rows of dh as well."""
+    lib = _lib.load()
+    dp, ld_dh = _mat(dh, "dh")
+    zp, ld_z = _mat(z, "z")
+    m = z.size(0) if m is None else int(m)
+    n = z.size(1)
+    if dz is None:
+        dz = torch.empty((m, n), dtype=torch.float32, device=z.device)
+    op, ld_dz = _mat(dz, "dz")
+    if dh.size(0) < m or dh.size(1) != n or dz.size(0) < m or dz.size(1) != n or z.size(0) < m:
+        raise RuntimeError("l2norm_relu_bwd_z: bad buffers")
+    rc = lib.sage_l2norm_relu_bwd_z(dp, ld_dh, zp, ld_z, 1 if relu else 0, m, _count(m_dev, "m_dev"), n, op, ld_dz,
+                                    1 if clear_dh else 0, _stream())
+    _lib.check(rc, "sage_l2norm_relu_bwd_z")
+    return dz
+
+
 def softmax_xent(logits, labels, label_rows=None, m=None, grad_scale=1.0, loss=None,
                  dlogits=None, want_grad=True, checked=False, row_loss=None):
     """Mean cross-entropy + gradient (reference fig2a/runners/graphsage_runners.py:43).
@@ -786,10 +806,12 @@ def logit_layer_supported(h, n):
 
 
 def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_rows, agg, y, inv_norm, dz,
-                    row_loss, grad_scale=1.0):
+                    row_loss, grad_scale=1.0, h_root=None):
     """The last SAGE layer on the m seed rows + normalise + cross entropy + d loss / d z in one
     launch (reference layers/sage.py:99-134 + fig2a/runners/graphsage_runners.py:41-43); all
-    buffers are the caller's (static-shape engine).  agg [m, h] is kept for the weight gradients."""
+    buffers are the caller's (static-shape engine).  agg [m, h] is kept for the weight gradients.
+    h_root [>= m, h]: h_rows holds the previous layer's PRE-activation rows; the kernel takes
+    every row through relu(normalize(.)) itself and stores the seeds' activations there."""
     lib = _lib.load()
     hp, ld_h = _mat(h_rows, "h_rows")
     wlp, ld_wl = _mat(w_l, "w_l")
@@ -805,11 +827,14 @@ def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_row
             or (inv_norm is not None and inv_norm.numel() < m) \
             or (label_rows is not None and label_rows.numel() < m) or (label_rows is None and labels.numel() < m):
         raise RuntimeError("logit_layer_fwd: bad buffers")
+    rp, ld_root = (None, 0) if h_root is None else _mat(h_root, "h_root")
+    if h_root is not None and (h_root.size(0) < m or h_root.size(1) != h):
+        raise RuntimeError("logit_layer_fwd: bad h_root buffer")
     rc = lib.sage_logit_layer_fwd(hp, ld_h, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), m, h,
                                   REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n, _vec(labels, torch.int64, "labels"),
                                   _vec(label_rows, torch.int64, "label_rows", allow_none=True), float(grad_scale),
                                   ap, ld_agg, yp, ld_y, _vec(inv_norm, torch.float32, "inv_norm", allow_none=True),
-                                  dp, ld_dz, _vec(row_loss, torch.float32, "row_loss"), _stream())
+                                  dp, ld_dz, _vec(row_loss, torch.float32, "row_loss"), rp, ld_root, _stream())
     _lib.check(rc, "sage_logit_layer_fwd")
 
 

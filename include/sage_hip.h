@@ -348,6 +348,15 @@ int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_
                          const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
                          int clear_dh /* 1: dh rows are zeroed after use (consume-and-clear) */,
                          void* stream);
+/* The same gradient from the PRE-normalisation rows z, for a forward that kept neither y nor
+ * inv_norm (sage_logit_layer_fwd with h_root: the rows were normalised on their way into the
+ * class-logit kernel; models/graphsage.py:47-48 + layers/sage.py:131-132 differentiated):
+ * y = z / max(||z||, 1e-12) is recomputed per row, then dz as above.  z is handed back ZEROED
+ * (its producer adds stream-K partial sums into it), dh too if clear_dh.  n a multiple of 4,
+ * at most 1024, rows 16-byte aligned (else SAGE_ELIMIT); dz and dh must not alias z. */
+int sage_l2norm_relu_bwd_z(float* dh, sage_i64 ld_dh, float* z, sage_i64 ld_z, int relu_mask,
+                           sage_i64 m, const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
+                           int clear_dh, void* stream);
 
 /* Gradient through the ReLU of the pool Linear, relu(pool(x_j)) at layers/sage.py:202,206 — what
  * autograd's threshold_backward computes:  dz[r, :] = out[r, :] > 0 ? dout[r, :] : 0  for r < m
@@ -450,7 +459,14 @@ int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg
                          const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
                          const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
                          float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
-                         float* row_loss, void* stream);
+                         float* row_loss,
+                         float* h_root /* NULL, or [m, h]: h_rows then holds the previous layer's
+                                          PRE-activation rows — every row read goes through
+                                          relu(z / max(||z||, 1e-12)) first (what
+                                          sage_l2norm_relu_fwd would have stored), and the seeds'
+                                          own activations are written here for the root term's
+                                          weight gradient; must not alias h_rows */,
+                         sage_i64 ld_h_root, void* stream);
 int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
                          sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
                          const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,

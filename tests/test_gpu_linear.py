@@ -681,6 +681,66 @@ def test_logit_layer_fused_matches_separate_kernels(dev, reduce, h, n):
     torch.testing.assert_close(dh.double(), hr.grad, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("reduce,h,n", [("mean", 256, 41), ("sum", 64, 7), ("mean", 512, 40), ("mean", 36, 5),
+                                        ("mean", 1024, 10)])
+def test_logit_layer_on_preactivation_rows(dev, reduce, h, n):
+    """h_root given: the kernel reads the previous layer's PRE-activation rows z and takes every
+    row through relu(normalize(.)) itself — against sage_l2norm_relu_fwd followed by the plain
+    call, including an all-zero row (norm clamped by eps) and a row of negatives (relu leaves
+    nothing); sage_l2norm_relu_bwd_z against sage_l2norm_relu_bwd on what that forward kept."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(12)
+    m, n_src = 77, 400
+    ldh = (h + 15) // 16 * 16
+    z = torch.randn(n_src, ldh, generator=g, device=dev)[:, :h]
+    z[7] = 0.0
+    z[9] = -z[9].abs()
+    z[2] *= 1e-20            # a seed row whose norm sits below eps
+    deg = torch.randint(0, 30, (m,), generator=g, device=dev)
+    deg[3], deg[5] = 0, 70
+    seg_ptr = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    seg_ptr[1:] = deg.cumsum(0)
+    src = torch.randint(0, n_src, (int(seg_ptr[-1]),), generator=g, device=dev)
+    src[:3] = torch.tensor([7, 9, 2], device=dev)
+    wbuf = torch.randn(2 * n, ldh, generator=g, device=dev) * 0.2
+    w_l, w_r = wbuf[:n, :h], wbuf[n:, :h]
+    labels = torch.randint(0, n, (m,), generator=g, device=dev)
+
+    def bufs():
+        return (torch.zeros(m, ldh, device=dev)[:, :h], torch.zeros(m, 64, device=dev)[:, :n],
+                torch.zeros(m, device=dev), torch.zeros(m, 64, device=dev)[:, :n], torch.zeros(m, device=dev))
+    # reference: the normalise pass, then the kernel on its output
+    y_ref, h_ref, inv_ref = ops.l2norm_relu_fwd(z.clone(), True)
+    agg2, y2, inv2, dz2, rl2 = bufs()
+    ops.logit_layer_fwd(h_ref, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg2, y2, inv2, dz2, rl2)
+    # on the pre-activation rows
+    agg, y, inv, dz, rl = bufs()
+    h_root = torch.full((m, ldh), 7.0, device=dev)[:, :h]
+    ops.logit_layer_fwd(z, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=h_root)
+    torch.testing.assert_close(h_root, h_ref[:m], rtol=1e-6, atol=1e-30)
+    torch.testing.assert_close(agg, agg2, rtol=1e-6, atol=1e-7)      # same values, same order: equal up to fma contraction
+    torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rl, rl2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dz, dz2, rtol=1e-4, atol=1e-7)
+    with pytest.raises(RuntimeError, match="alias"):
+        ops.logit_layer_fwd(z, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=z)
+    # backward from z
+    dh = torch.randn(n_src, ldh, generator=g, device=dev)[:, :h]
+    for relu in (True, False):
+        want = ops.l2norm_relu_bwd(dh.clone(), y_ref, inv_ref, relu)
+        zc, dhc = z.clone(), dh.clone()
+        cnt = torch.tensor([n_src - 5], dtype=torch.int64, device=dev)
+        got = torch.full((n_src, ldh), 3.0, device=dev)[:, :h]
+        ops.l2norm_relu_bwd_z(dhc, zc, relu, m=n_src, m_dev=cnt, dz=got, clear_dh=True)
+        torch.testing.assert_close(got[:n_src - 5], want[:n_src - 5], rtol=1e-6, atol=1e-30)
+        assert float(got[n_src - 5:].min()) == 3.0                                  # rows beyond the device count untouched
+        assert float(zc[:n_src - 5].abs().max()) == 0.0 and float(dhc[:n_src - 5].abs().max()) == 0.0
+        assert torch.equal(zc[n_src - 5:], z[n_src - 5:]) and torch.equal(dhc[n_src - 5:], dh[n_src - 5:])
+    if h == 36:
+        with pytest.raises(RuntimeError, match="aligned"):
+            ops.l2norm_relu_bwd_z(dh.clone(), torch.zeros(n_src, 37, device=dev)[:, :36], True)
+
+
 def test_logit_layer_rejects_weights_beyond_lds(dev):
     from graphsage_amd import ops
     assert not ops.logit_layer_supported(512, 64) and ops.logit_layer_supported(512, 40)
