@@ -15,10 +15,13 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
     launch);
   * the class-logit layer of the supervised mean / sum step is two launches
     (sage_logit_layer_fwd / _bwd: reduce, both weight products, normalise, cross entropy and
-    their backward for the B seed rows);
+    their backward for the B seed rows), and the hidden layer below it is never normalised as
+    a whole: the forward kernel normalises the rows it gathers, the backward works from the
+    pre-activation rows (sage_l2norm_relu_bwd_z);
   * the pooling aggregators keep P = relu(pool(x)) per SOURCE row of a layer in a static buffer
     and route d agg back through the reduce and the ReLU in one edge pass
-    (sage_pool_linear_fwd / sage_pool_max_bwd / sage_pool_mean_bwd).
+    (sage_pool_linear_fwd / sage_pool_max_bwd / sage_pool_mean_bwd); their large weight
+    gradients run on a forked stream beside that pass.
 """
 import contextlib
 import os
