@@ -12,6 +12,7 @@ engine; every other aggregator runs the module path (autograd Functions over the
     python -m graphsage_amd.experiments.fig2a --dataset cora --aggregators mean max_pool
 """
 import argparse
+import os
 import json
 import time
 
@@ -108,7 +109,12 @@ def run(aggregator, dataset=None, num_epochs=None, batch_size=BATCH_SIZE, k1=K1,
         from ..engine import SageTrainEngine
         graph = train_loader.neighbor_sampler.graph
         engine = SageTrainEngine(model, train_loader.neighbor_sampler, graph.features(data), graph.labels(data),
-                                 batch_size, lr=LEARNING_RATE)
+                                 batch_size, lr=LEARNING_RATE,
+                                 overlap_gather=aggregator != 'gcn' and not os.environ.get('SAGE_FIG2A_SERIAL'))
+        # (bench.py's headline schedule: the next batch's layer-0 gather beside this batch's step.  Measured
+        # through this harness, 4 epochs at the Reddit shape, seconds per batch: mean 0.269-0.278 against
+        # 0.282-0.287 ms on one stream, max 0.289 against 0.302; gcn 0.320 against 0.267 — there it stays off.
+        # The pooling engine ignores it.)
     train_time = test_time = 0.0
     loss = test_acc = None
     for epoch in range(1, num_epochs + 1):

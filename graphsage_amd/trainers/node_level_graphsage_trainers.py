@@ -86,7 +86,9 @@ def _engine_for(trainer, unsup, explicit):
     graph = sampler.graph
     return SageTrainEngine(trainer.model, sampler, graph.features(trainer.data), graph.labels(trainer.data),
                            trainer.train_loader.batch_size, lr=g['lr'], betas=g['betas'], eps=g['eps'],
-                           weight_decay=g['weight_decay'], unsup=unsup, **_dp_engine())
+                           weight_decay=g['weight_decay'], unsup=unsup,
+                           overlap_gather=trainer.model.aggregator != 'gcn',      # (experiments/fig2a.py says why)
+                           **_dp_engine())
 
 
 class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer):
