@@ -844,12 +844,12 @@ class SageTrainEngine:
         for b in range(nb):
             nxt = seeds[(b + d) * self.B:(b + d + 1) * self.B] if b + d < nb else None
             loss = self.pipelined_step(nxt, counter(b + d) if nxt is not None else None)
-            total += loss * self.B
+            total.add_(loss.view(1), alpha=self.B)      # (one launch, not a multiply and an add)
         self.flush()
         if tail:
             rest = seeds[nb * self.B:]
             padded = torch.cat([rest, rest[:1].expand(self.B - tail)]).contiguous()
-            total += self.step(padded, counter=counter(nb), valid=tail) * tail
+            total.add_(self.step(padded, counter=counter(nb), valid=tail).view(1), alpha=tail)
         # mean over the examples, as the reference accumulates it (fig2a/runners/graphsage_runners.py:48-50)
         return total / (nb * self.B + tail)
 
