@@ -16,6 +16,7 @@
 #include "common.h"
 
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -39,6 +40,22 @@ __device__ inline float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
+}
+// Sum over the 64 lanes as a wave-uniform value, on the DPP path (no LDS crossbar traffic: the
+// butterflies above go through ds_bpermute): xor 1, xor 2, mirror within 8, mirror within 16 give
+// every lane its 16-lane row's sum; row_bcast:15 / :31 chain the four rows into lane 63.
+__device__ inline float wave_total(float v) {
+  auto dpp_add = [](float x, auto ctrl, auto row_mask) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
+                                                                     decltype(row_mask)::value, 0xf, false));
+  };
+  v = dpp_add(v, std::integral_constant<int, 0xb1>{}, std::integral_constant<int, 0xf>{});     // quad_perm:[1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4e>{}, std::integral_constant<int, 0xf>{});     // quad_perm:[2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});    // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});    // row_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});    // row_bcast:15 into rows 1, 3
+  v = dpp_add(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});    // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ inline float wave_max(float v) {
 #pragma unroll
@@ -104,7 +121,7 @@ struct WeightStage {
 
 // NV = H / 256 (a lane holds NV float4 of a row: columns 4 (lane + 64 v) ..)
 // PRE: hrows holds the previous layer's PRE-activation rows z; a row becomes relu(z / max(|z|, eps))
-// in registers on its way in (one more butterfly per row, 16 rows at a time), so the previous
+// in registers on its way in (one DPP reduction per row, 16 rows at a time), so the previous
 // layer's normalise pass — 54 MB and a launch — is not run at all; the seeds' own activations
 // are written to h_root for the root term's weight gradient.
 template <int NV, bool FULL, bool PRE>      // FULL: h == 256 NV, no lane is ever out of the row
@@ -134,7 +151,8 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   auto activate = [&](float4 (&r)[NV], float ss) {      // relu(z / max(|z|, eps)), ss = |z|^2 over the wave
     // (times the reciprocal, not a division per element as the normalise pass does it: within an
     // ulp of that, and a quarter of this path's instructions)
-    const float inv = 1.f / fmaxf(sqrtf(ss), kNormEps);
+    // v_rsq_f32 (1 ulp) and a clamp instead of an IEEE square root and a division: 1 / max(|z|, eps)
+    const float inv = fminf(__builtin_amdgcn_rsqf(ss), 1.f / kNormEps);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
       r[v].x = fmaxf(r[v].x * inv, 0.f);
@@ -169,7 +187,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   LOGIT_STAMP(0, 1);
   bool staged = false;
   if constexpr (PRE) {
-    activate(root, wave_sum(sumsq(root)));
+    activate(root, wave_total(sumsq(root)));
     if (live && h_root != nullptr) {
       float4* hp = reinterpret_cast<float4*>(h_root + t * ld_h_root);
 #pragma unroll
@@ -205,12 +223,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
         if constexpr (PRE) {
           float ss[kRowsInFlight];
 #pragma unroll
-          for (int r = 0; r < kRowsInFlight; ++r) ss[r] = r0 + r < chunk ? sumsq(x[r]) : 0.f;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) {      // the rows' butterflies side by side
-#pragma unroll
-            for (int r = 0; r < kRowsInFlight; ++r) ss[r] += __shfl_xor(ss[r], o);
-          }
+          for (int r = 0; r < kRowsInFlight; ++r) ss[r] = wave_total(r0 + r < chunk ? sumsq(x[r]) : 0.f);
 #pragma unroll
           for (int r = 0; r < kRowsInFlight; ++r) {
             if (r0 + r < chunk) activate(x[r], ss[r]);

@@ -28,7 +28,9 @@ int main() {
   CK(hipMemcpy(dh_, h.data(), h.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice));
   CK(hipMemcpy(dseg, seg.data(), seg.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dsrc, src.data(), src.size() * 8, hipMemcpyHostToDevice));
   CK(hipMemcpy(dlab, lab.data(), lab.size() * 8, hipMemcpyHostToDevice)); CK(hipMemset(dgrad, 0, h.size() * 4));
-  auto fwd = [&]() { return sage_logit_layer_fwd(dh_, H, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dlab, nullptr, 1.f, agg, H, y, 64, inv, dz, 64, rl, nullptr); };
+  float* hroot; CK(hipMalloc(&hroot, (size_t)M * H * 4));
+  const bool pre = getenv("PRE") != nullptr;      // PRE=1: the rows are pre-activation rows, normalised on their way in
+  auto fwd = [&]() { return sage_logit_layer_fwd(dh_, H, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dlab, nullptr, 1.f, agg, H, y, 64, inv, dz, 64, rl, pre ? hroot : nullptr, H, nullptr); };
   auto bwd = [&]() { return sage_logit_layer_bwd(dz, 64, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dgrad, H, rl, loss, nullptr); };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms;
