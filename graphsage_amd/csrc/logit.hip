@@ -44,19 +44,31 @@ __device__ inline float wave_sum(float v) {
 // Sum over the 64 lanes as a wave-uniform value, on the DPP path (no LDS crossbar traffic: the
 // butterflies above go through ds_bpermute): xor 1, xor 2, mirror within 8, mirror within 16 give
 // every lane its 16-lane row's sum; row_bcast:15 / :31 chain the four rows into lane 63.
-__device__ inline float wave_total(float v) {
-  auto dpp_add = [](float x, auto ctrl, auto row_mask) {
-    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value,
-                                                                     decltype(row_mask)::value, 0xf, false));
+template <typename Op>
+__device__ inline float wave_reduce_dpp(float v, Op op) {
+  auto step = [&](float x, auto ctrl, auto row_mask) {
+    // (masked rows and invalid source lanes keep x itself: op(x, x) == x for max, and the sum passes 0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, op.neutral(x)), __builtin_bit_cast(int, x),
+                                                                 decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false));
   };
-  v = dpp_add(v, std::integral_constant<int, 0xb1>{}, std::integral_constant<int, 0xf>{});     // quad_perm:[1,0,3,2]
-  v = dpp_add(v, std::integral_constant<int, 0x4e>{}, std::integral_constant<int, 0xf>{});     // quad_perm:[2,3,0,1]
-  v = dpp_add(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});    // row_half_mirror
-  v = dpp_add(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});    // row_mirror
-  v = dpp_add(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});    // row_bcast:15 into rows 1, 3
-  v = dpp_add(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});    // row_bcast:31 into rows 2, 3
+  v = op(v, step(v, std::integral_constant<int, 0xb1>{}, std::integral_constant<int, 0xf>{}));     // quad_perm:[1,0,3,2]
+  v = op(v, step(v, std::integral_constant<int, 0x4e>{}, std::integral_constant<int, 0xf>{}));     // quad_perm:[2,3,0,1]
+  v = op(v, step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{}));    // row_half_mirror
+  v = op(v, step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{}));    // row_mirror
+  v = op(v, step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{}));    // row_bcast:15 into rows 1, 3
+  v = op(v, step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{}));    // row_bcast:31 into rows 2, 3
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+struct SumOp {
+  __device__ float operator()(float a, float b) const { return a + b; }
+  __device__ float neutral(float) const { return 0.f; }
+};
+struct MaxOp {
+  __device__ float operator()(float a, float b) const { return fmaxf(a, b); }
+  __device__ float neutral(float x) const { return x; }
+};
+__device__ inline float wave_total(float v) { return wave_reduce_dpp(v, SumOp{}); }
+__device__ inline float wave_top(float v) { return wave_reduce_dpp(v, MaxOp{}); }
 __device__ inline float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -322,20 +334,20 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   // normalise + cross entropy + d loss / d z on the n <= 64 values, one per lane (the formulas of
   // logits_xent_fused_kernel, rowops.hip)
   const bool has = lane < n;
-  const float ss = wave_sum(has ? zc * zc : 0.f);
+  const float ss = wave_total(has ? zc * zc : 0.f);
   const float denom = fmaxf(sqrtf(ss), kNormEps);
   const float inv = 1.f / denom;
   const bool clamped = inv >= 1.f / kNormEps;
   const float yv = zc / denom;
-  const float mx = wave_max(has ? yv : -INFINITY);
-  const float se = wave_sum(has ? expf(yv - mx) : 0.f);
+  const float mx = wave_top(has ? yv : -INFINITY);
+  const float se = wave_total(has ? expf(yv - mx) : 0.f);
   const float lse = mx + logf(se);
   const float scale = grad_scale / static_cast<float>(m);
   float g = has ? expf(yv - lse) : 0.f;
   if (has && lane == lab) g -= 1.f;
   g *= scale;
-  const float at_label = wave_sum(has && lane == lab ? yv : 0.f);
-  const float dot = clamped ? 0.f : wave_sum(has ? yv * g : 0.f);
+  const float at_label = wave_total(has && lane == lab ? yv : 0.f);
+  const float dot = clamped ? 0.f : wave_total(has ? yv * g : 0.f);
   if (lane == 0) {
     if (inv_norm != nullptr) inv_norm[t] = inv;
     row_loss[t] = (lab >= 0 && lab < n) ? lse - at_label : 0.f;
