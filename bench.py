@@ -50,7 +50,9 @@ def parse():
     ap.add_argument("--fanout", type=int, nargs="+", default=[25, 10])
     ap.add_argument("--aggregator", default="mean")
     ap.add_argument("--lr", type=float, default=1e-3)
-    ap.add_argument("--cpu-steps", type=int, default=6, help="timed CPU-baseline steps (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=20,
+                    help="timed CPU-baseline steps (0 = skip); SURVEY 8(d): at least 20 after 5 warm-ups, median")
+    ap.add_argument("--cpu-warmup", type=int, default=5, help="untimed CPU-baseline steps in front of the timed ones")
     ap.add_argument("--group", type=int, default=4,
                     help="batches per cross-stream synchronisation of the eager pipeline (engine `group`)")
     ap.add_argument("--no-variant", action="store_true",
@@ -74,6 +76,10 @@ def parse():
                          "are reported separately, never as the headline.  unsup: the unsupervised "
                          "trainer's step (:104-117), loss = the random-walk term alone, embedding width = "
                          "--hidden (BASELINE.json configs[4] with --workload products)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one GPU: run the data-parallel control flow anyway (a 1-rank RCCL group, asynchronous "
+                         "all-reduce on RCCL's stream, deferred Adam, serial schedule) — measures what that control "
+                         "flow costs per step before any link latency; informational, never the driver's command")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from HIP graphs instead of launching every kernel eagerly "
                          "(same arithmetic; measured 2-3 %% slower than eager on MI355X / ROCm 7.2)")
@@ -81,9 +87,22 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(data_cpu, colptr, row, seeds_list, fanout, layers, steps, lr):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(data_cpu, colptr, row, seeds_list, fanout, layers, steps, lr, warmup=5):
     """The oracle's restatement of the reference step, as written (unfused, all sampled rows
-    through both layers), on the host cores.  Returns (seeds/s, cores, description)."""
+    through both layers), on the host cores: `warmup` untimed steps, then `steps` timed ones.
+    Returns (seeds/s from the MEDIAN step time, cores, median s/step, timed steps, mean s/step)."""
     import numpy as np
     import torch.nn.functional as F
 
@@ -101,7 +120,7 @@ def cpu_baseline(data_cpu, colptr, row, seeds_list, fanout, layers, steps, lr):
     opt = torch.optim.Adam(params, lr=lr)
     samp = sampler_c.neighbor_sample if sampler_c.available() else sampler.neighbor_sample
     times = []
-    for i, seeds in enumerate(seeds_list[: steps + 1]):
+    for i, seeds in enumerate(seeds_list[: steps + warmup]):
         t0 = time.perf_counter()
         node, src, dst, eid, _, _ = samp(colptr, row, seeds, fanout, 0, i)
         opt.zero_grad()
@@ -110,9 +129,10 @@ def cpu_baseline(data_cpu, colptr, row, seeds_list, fanout, layers, steps, lr):
         loss.backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-    timed = times[1:] if len(times) > 1 else times          # first step = warm-up
-    per_step = sum(timed) / len(timed)
-    return len(seeds_list[0]) / per_step, cores, per_step, len(timed)
+    timed = times[warmup:] if len(times) > warmup else times[-1:]
+    per_step = sorted(timed)[len(timed) // 2] if len(timed) % 2 else \
+        0.5 * (sorted(timed)[len(timed) // 2 - 1] + sorted(timed)[len(timed) // 2])
+    return len(seeds_list[0]) / per_step, cores, per_step, len(timed), sum(timed) / len(timed)
 
 
 def trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank):
@@ -174,8 +194,10 @@ def bracket_contractions(ops):
         inner = getattr(ops, name)
 
         def wrapped(*a, **kw):
+            if not rec["on"]:
+                return inner(*a, **kw)
             fl = flops_of(*a, **kw)
-            if not rec["on"] or fl < 1e9:
+            if fl < 1e9:
                 return inner(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -212,12 +234,21 @@ def bracket_contractions(ops):
 def mfma_roofline(rec, steps, gemm_mode):
     t_ms = sum(a.elapsed_time(b) for a, b in rec["pairs"])
     tf = rec["flops"] / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
+    # what an event pair with nothing between its records reads on this stream (the bracket's own cost)
+    eb = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    for a0, b0 in eb:
+        a0.record()
+        b0.record()
+    torch.cuda.synchronize()
+    empty_ms = sum(a0.elapsed_time(b0) for a0, b0 in eb) / len(eb)
     # bf16x3: six bf16 MFMA products per fp32 product, so the fp32-equivalent peak is bf16 / 6
     peak = MFMA_PEAK_TFLOPS["bf16"] / 6.0 if gemm_mode == "bf16x3" else MFMA_PEAK_TFLOPS["f32"]
     return {"bound": "mfma", "kernel": "MFMA contractions above 1 GFLOP (gemm_x3_kernel / gemm_x3_dw_kernel / gemm_kernel)",
             "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
             "traffic": None, "flops_per_step": rec["flops"] / steps,
             "gemm_ms_per_step": round(t_ms / steps, 4), "launches_per_step": len(rec["pairs"]) / steps,
+            "avg_launch_us": round(t_ms / max(len(rec["pairs"]), 1) * 1e3, 2),
+            "empty_event_pair_us": round(empty_ms * 1e3, 2),
             "timing": "HIP events recorded around each call on its stream (fp32-equivalent flops; "
                       "peak = bf16 dense peak / 6 products in bf16x3 mode)"}
 
@@ -273,8 +304,28 @@ def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_
         "variant": "module-path"}), flush=True)
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the
+    N ranks as fresh child processes through torch.distributed.run and relay their output and
+    exit code.  This process has not touched the GPU (importing torch does not initialise it) and
+    never replaces itself — the ranks are children, rank 0's JSON line goes to the inherited
+    stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:          # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this host driver
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -299,6 +350,14 @@ def main():
         raise SystemExit(f"{world} ranks on a node with {torch.cuda.device_count()} visible GPUs: RCCL needs one GPU per rank")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    force_coll = args.force_collective and world == 1
+    if force_coll:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(s_.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -339,7 +398,7 @@ def main():
     torch.cuda.empty_cache()
     init_layers = [{k: getattr(m, k).weight.detach().cpu().clone() for k in ("lin_l", "lin_r") if hasattr(m, k)}
                    for m in model.layers]
-    pg = torch.distributed.group.WORLD if world > 1 else None
+    pg = torch.distributed.group.WORLD if (world > 1 or force_coll) else None
     if args.variant == "trainer-module":
         return trainer_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, world, rank)
     unsup = {"trainer": True, "unsup": "only"}.get(args.variant, False)
@@ -368,7 +427,7 @@ def main():
     def make_engine(mdl, overlap):
         return SageTrainEngine(mdl, NeighborSampler.from_graph(graph, K, seed=0), feats, labels, B, lr=args.lr,
                                world_size=world, process_group=pg, overlap_gather=overlap, group=args.group,
-                               unsup=unsup)
+                               unsup=unsup, force_collective=force_coll)
 
     def run_schedule(engine, settle, warmup, steps, probe_gather, graph_replay=False):
         """settle + warmup untimed steps, then `steps` timed ones bracketed by barrier + synchronize;
@@ -447,7 +506,10 @@ def main():
         return 4.0 * Fdim * e_b + 4.0 * Fdim * t1 + 8.0 * (2 * e_b + t1 + launches)
 
     base = max(args.settle_steps, 0)
-    overlapped = not args.serial and not use_graph and not pooling
+    # One GPU: the overlapped schedule.  Data parallel: the serial one — the layer-0 gather of
+    # batch s+1 then sits on the main stream between the all-reduce launch of step s and its
+    # Adam step and covers the collective (graphsage_amd/engine.py).
+    overlapped = not args.serial and not use_graph and not pooling and world == 1 and not force_coll
     import copy
     # 1. the roofline probe: serial schedule (every kernel of a step on ONE stream), where the
     #    HBM-bound layer-0 gather has the chip to itself and its event-timed duration is its own
@@ -469,8 +531,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        roofline = None
-        if pooling and world == 1 and not args.no_probe:
+        roofline = roofline_mfma = None
+        if world == 1 and not args.no_probe and not force_coll and args.variant == "fig2a":
             # MFMA roofline of the contractions: a short run of the same steps with every call
             # going through the wrappers of ops.py (no call tapes), each contraction above
             # 1 GFLOP bracketed by a HIP event pair
@@ -487,10 +549,12 @@ def main():
                 pe.step(seeds_of(s_), counter_of(s_))
             torch.cuda.synchronize()
             rec["on"] = False
-            roofline = mfma_roofline(rec, n_probe, gemm_mode)
-            roofline["schedule"] = (f"separate run of {n_probe} steps on one stream without call tapes "
-                                    "(the headline run forks the large weight gradients beside the aggregate path)")
+            roofline_mfma = mfma_roofline(rec, n_probe, gemm_mode)
+            roofline_mfma["schedule"] = (f"separate run of {n_probe} steps on one stream without call tapes "
+                                         "(every contraction alone on the chip)")
             del pe
+            if pooling:      # there the contractions ARE the dominant kernels
+                roofline, roofline_mfma = roofline_mfma, None
         if probe:
             src = probe_res if probe_res is not None else res
             n_launch = src["gather_ms"].numel()
@@ -550,12 +614,14 @@ def main():
         if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a" and args.aggregator == "mean":   # the oracle times fig2a's step
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
             colptr, row = graph.colptr.cpu().numpy(), graph.row.cpu().numpy()
-            seeds_list = [train[i * B:(i + 1) * B].numpy() for i in range(args.cpu_steps + 1)]
-            v, cores, per_step, n_timed = cpu_baseline((x_cpu, y_cpu), colptr, row, seeds_list, K, init_layers,
-                                                       args.cpu_steps, args.lr)
+            seeds_list = [train[i * B:(i + 1) * B].numpy() for i in range(args.cpu_steps + args.cpu_warmup)]
+            v, cores, per_step, n_timed, mean_step = cpu_baseline((x_cpu, y_cpu), colptr, row, seeds_list, K,
+                                                                  init_layers, args.cpu_steps, args.lr, args.cpu_warmup)
             cpu = {"value": round(v, 1), "unit": "seed nodes/s", "cores": cores, "kind": "port",
-                   "sample": f"{n_timed} timed steps (+1 warm-up) of the same workload, B={B}, "
-                             f"{per_step:.2f} s/step, oracle restatement of the reference step as written"}
+                   "cpu_model": cpu_model(),
+                   "sample": f"{n_timed} timed steps after {args.cpu_warmup} warm-up steps of the same workload, B={B}, "
+                             f"median {per_step:.3f} s/step (mean {mean_step:.3f}), oracle restatement of the "
+                             "reference step as written"}
         out = {
             "metric": "Reddit GraphSAGE-mean 25/10 fwd+bwd seed nodes/s; gather GB/s vs HBM peak",
             "value": round(value, 1), "unit": "seed nodes/s", "n_gpus": world, "steps": args.steps,
@@ -567,21 +633,23 @@ def main():
                                                        "unsup": "UNSUPERVISED trainer step (random-walk loss, 3 forwards)"}.get(
                                        args.variant, "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
             "schedule": ("HIP-graph replay" if use_graph else
                          "overlapped: layer-0 gather of batch s+1 on the side stream beside batch s" if overlapped
-                         else "serial: every kernel of a step on one stream"),
+                         else "serial: every kernel of a step on one stream" if (world == 1 and not force_coll)
+                         else "data parallel, serial: all-reduce launch (RCCL stream) -> layer-0 gather of the next "
+                              "batch -> wait -> Adam -> forward contraction"),
             "gemm_mode": gemm_mode + (" (fp32 operands split into 3 bf16 terms, 6 MFMA products, fp32 accumulation)"
                                       if gemm_mode == "bf16x3" else " (v_mfma_f32_32x32x2_f32)"),
             "variant_gemm_f32": variant_f32,
             "final_loss": round(loss, 5), "setup_s": round(setup_s, 1), "settle_steps": base_main,
             "avg_nodes_per_batch": float(st[ops.ST_NODES]) / max(float(st[ops.ST_HOP_NODES]) / B, 1.0),
             "avg_edges_per_batch": float(st[ops.ST_EDGES]) / max(float(st[ops.ST_HOP_NODES]) / B, 1.0),
-            "variant": args.variant, "hip_graph": use_graph,
+            "variant": args.variant, "hip_graph": use_graph, "force_collective": bool(force_coll),
             "host_enqueue_ms_per_step": round(res["issued"] / args.steps * 1e3, 4), "overlap_gather": bool(overlapped),
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_coll:
         torch.distributed.destroy_process_group()
 
 

@@ -45,11 +45,12 @@ def _all_reduce_staged(flat_grad, group):
     flat_grad.reshape(-1).copy_(host, non_blocking=True)     # ordered on the current stream
 
 
-def all_reduce_flat(flat_grad, group=None, async_op=False):
+def all_reduce_flat(flat_grad, group=None, async_op=False, force=False):
     """Sum the flat gradient buffer over ranks (the mean's 1/world is fused into Adam).
     async_op=True returns the work handle (None when there is nothing to reduce): the collective
-    runs on the backend's own stream and handle.wait() orders the current stream after it."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    runs on the backend's own stream and handle.wait() orders the current stream after it.
+    force: issue the collective in a one-rank group as well (the engine's force_collective)."""
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         if flat_grad.is_cuda and dist.get_backend(group) == "gloo":
             _all_reduce_staged(flat_grad, group)
             return _Done() if async_op else flat_grad
@@ -70,10 +71,10 @@ class PendingReduce:
         self.work = None
         self.active = False
 
-    def launch(self, flat_grad, group=None):
+    def launch(self, flat_grad, group=None, force=False):
         if self.active:
             raise RuntimeError("the previous step's all-reduce has not been completed")
-        self.work = all_reduce_flat(flat_grad, group, async_op=True)
+        self.work = all_reduce_flat(flat_grad, group, async_op=True, force=force)
         self.active = True
 
     def complete(self):

@@ -133,7 +133,7 @@ class SageTrainEngine:
 
     def __init__(self, model, sampler, features, labels, batch_size, lr=1e-3, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=0.0, world_size=1, process_group=None, overlap_gather=False,
-                 keep_grads=False, group=4, unsup=False):
+                 keep_grads=False, group=4, unsup=False, force_collective=False):
         if model.aggregator not in _REDUCE:
             raise NotImplementedError(f"engine supports {sorted(_REDUCE)}, got {model.aggregator}")
         self.model = model
@@ -148,6 +148,18 @@ class SageTrainEngine:
             raise NotImplementedError("engine: the pooling aggregators run the supervised (fig2a) step only")
         if self.pool:
             overlap_gather = False    # the layer-0 gather reads P, which needs this step's weights
+        # Data parallel: the gradient all-reduce of step i is launched behind the backward's last
+        # kernel and its Adam step sits in front of the first kernel of step i+1 that reads the
+        # weights.  The one piece of weight-free work that can run on the main stream in between
+        # is the layer-0 gather of batch i+1 (53 us of HBM traffic at the Reddit shape against a
+        # latency-bound 1.3 MB collective): with a collective the engine therefore runs the
+        # SERIAL schedule — all-reduce launch -> gather -> wait -> Adam -> forward contraction —
+        # and not overlap_gather, whose gather of batch i+1 has already run beside step i's
+        # contraction and leaves the collective fully exposed.  force_collective: take the
+        # collective branch with one rank as well (tests: a 1-rank RCCL group on the one-GPU box).
+        self.collective = world_size > 1 or bool(force_collective)
+        if self.collective:
+            overlap_gather = False
         # The class-logit layer (the last SAGE layer on the B seed rows) in one launch each way
         # (sage_logit_layer_fwd / _bwd) instead of gather / split-K contraction / fused loss and
         # d-input pair / scatter-add / loss mean: supervised step, mean or sum, two or more layers
@@ -282,6 +294,7 @@ class SageTrainEngine:
         self._tapes = {}        # recorded C-ABI call sequences, keyed by (what, slot, ..., stream)
         self.use_tapes = True   # False: every call goes through the validating wrappers of ops.py (measurement hooks)
         self._pending = PendingReduce()   # data parallel: the gradient all-reduce not yet applied
+        self.trace = None       # tests: a list that receives the name of every piece of a step as it is ENQUEUED
         # data parallel: the host may run at most `run_ahead` steps (= un-waited collectives)
         # ahead of the device: it blocks on the event recorded that many steps ago
         self.run_ahead = 8
@@ -401,6 +414,7 @@ class SageTrainEngine:
         torch.cuda.synchronize()
         self._stamp = int(self.ctrl[ops.CTRL_STAMP]) + 1      # captured with host stamp 1 + ctrl
         self.graphs = None
+        self._tapes.clear()        # (recorded again on the next eager call: one stream, no fork)
         self._main_touched = True
 
     def _taped(self, what, slot, fn, stream=None):
@@ -428,10 +442,15 @@ class SageTrainEngine:
         else:
             _lib.replay(tape)
 
+    def _note(self, what):
+        if self.trace is not None:
+            self.trace.append(what)
+
     def gather_layer0(self, slot=0, stream=None, events=None):
         """Layer-0 gather of the batch in `slot`.  events = (start, stop) raw HIP event handles:
         the launch carries them (sage_gather_reduce_fwd_timed), for a caller that measures this
         kernel (bench.py's roofline probe)."""
+        self._note('gather0')
         if events is None:
             self._taped('gather0', slot, lambda: self._gather_layer0(slot), stream)
             return
@@ -476,6 +495,7 @@ class SageTrainEngine:
                             dpre=a['dpre'])
 
     def forward_backward(self, slot=0, skip_gather0=False):
+        self._note('forward_backward')
         self.last_slot = slot
         if self.unsup:
             self.make_pos_neg(slot, self.slot_counter[slot])
@@ -694,10 +714,11 @@ class SageTrainEngine:
         ops.random_nodes(self.graph.num_nodes, self.pos_id.numel(), self.rng_seed, counter, out=self.neg_id)
 
     def all_reduce(self):
-        if self.world_size > 1:
-            all_reduce_flat(self.grad, self.pg)
+        if self.collective:
+            all_reduce_flat(self.grad, self.pg, force=True)
 
     def optimizer_step(self):
+        self._note('adam')
         par = self._adam_calls & 1
         self._adam_calls += 1
         self._taped('adam', par, lambda: self._optimizer_step(par))
@@ -759,9 +780,11 @@ class SageTrainEngine:
                     after_gather()
         self.gathered[slot] = True
 
-    def prefetch(self, seeds, counter, before_gather=None, after_gather=None, gather_events=None):
+    def prefetch(self, seeds, counter, before_gather=None, after_gather=None, gather_events=None, _in_step=False):
         """Sample `seeds` on the side stream into the next slot of the ring.  Call it `depth`
-        times before the first pipelined_step()."""
+        times before the first pipelined_step().  (_in_step: the call comes from inside
+        pipelined_step(), which has counted batch n_comp-1 as computed but not enqueued its
+        compute yet — a wait on the main stream taken now covers batch n_comp-2 at most.)"""
         self._require_eager("prefetch()")
         n = self.n_pref
         if n - self.n_comp >= self.depth:
@@ -773,7 +796,7 @@ class SageTrainEngine:
             # first use of the slot, serial step()/evaluate() calls in between, or an irregular
             # call sequence that no recorded event covers
             self.samp.wait_stream(main)
-            self.side_cons_seq = self.n_comp - 1
+            self.side_cons_seq = self.n_comp - (2 if _in_step else 1)
             self._main_touched = False
         elif need > self.side_cons_seq:
             self.samp.wait_event(self.cons_latest)      # once per group in steady state
@@ -822,6 +845,10 @@ class SageTrainEngine:
                 newest = self.n_pref - 1
                 main.wait_event(self.ready[newest % self.nslots])
                 self.main_ready_seq = newest
+            if self.pool:
+                # the pooling aggregators' "gather" starts with the pool Linear: it reads the
+                # weights, so the deferred Adam step of the previous batch goes in front of it
+                self.flush()
             if before_gather is not None:
                 before_gather()
             self.gather_layer0(p, events=gather_events)
@@ -829,14 +856,15 @@ class SageTrainEngine:
                 after_gather()
         self.n_comp = i + 1
         if next_seeds is not None:
-            self.prefetch(next_seeds, next_counter)
+            self.prefetch(next_seeds, next_counter, _in_step=True)
         # data parallel: the previous step's all-reduce has been running on the collective's own
         # stream while this step's sampler wait and (weight-free) layer-0 gather were enqueued;
         # its Adam step goes here, just before the first kernel that reads the weights
         self.flush()
         self.forward_backward(slot=p, skip_gather0=True)
-        if self.world_size > 1:
-            self._pending.launch(self.grad, self.pg)
+        if self.collective:
+            self._note('allreduce_launch')
+            self._pending.launch(self.grad, self.pg, force=True)
             # bound the host's run-ahead: with RCCL neither the launch nor wait() blocks the host
             ev = torch.cuda.Event()
             ev.record(main)
@@ -855,6 +883,8 @@ class SageTrainEngine:
         """Apply a deferred optimizer step.  Under data parallelism pipelined_step() returns with
         the gradient all-reduce in flight and applies Adam at the start of the next call (or
         here): call flush() before reading the weights."""
+        if self._pending.active:
+            self._note('allreduce_wait')
         if self._pending.complete():
             self.optimizer_step()
 
@@ -959,6 +989,7 @@ class SageTrainEngine:
         if self.overlap_gather or self.unsup:
             raise NotImplementedError("overlap_gather / unsup are options of the eager pipeline")
         self.pool_fork = None      # (the captured step stays on one stream)
+        self._tapes.clear()        # eager tapes hold calls bound to the fork stream
         self.flush()
         self.seed_pool = seed_pool.contiguous()
         self.split_gather = split_gather

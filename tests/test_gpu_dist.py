@@ -16,12 +16,12 @@ B, STEPS, FAN = 32, 4, [5, 3]
 LONG_STEPS = 80
 
 
-def _setup():
+def _setup(aggregator="mean"):
     from graphsage_amd.datasets import planted_partition
     from graphsage_amd.models import GraphSAGE
     data = planted_partition(1500, 30000, 24, 5, seed=8)
     torch.manual_seed(3)
-    model = GraphSAGE(24, 16, "mean", 2, 5)
+    model = GraphSAGE(24, 16, aggregator, 2, 5)
     train = torch.randperm(1500, generator=torch.Generator().manual_seed(1))[:2 * B * STEPS]
     return data, model, train
 
@@ -35,13 +35,13 @@ def _engine(data, model, dev, **kw):
                            graph.labels(data), B, lr=1e-2, **kw)
 
 
-def _worker(rank, world, port, out, long_run=False):
+def _worker(rank, world, port, out, long_run=False, aggregator="mean"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from graphsage_amd.dist import batch_counter, shard_seeds
     dev = torch.device("cuda:0")
-    data, model, train = _setup()
+    data, model, train = _setup(aggregator)
     if long_run:      # bench.py's loop shape: many steps, no loss read-back in between
         train = torch.randint(0, 1500, (2 * B * LONG_STEPS,), generator=torch.Generator().manual_seed(2))
     eng = _engine(data, model, dev, world_size=world, process_group=dist.group.WORLD)
@@ -82,12 +82,15 @@ def test_engine_data_parallel_many_steps_staged_allreduce(dev):
     assert sum(loss0[-8:]) < sum(loss0[:8])                # and it trains
 
 
-def test_engine_data_parallel_two_ranks(dev):
+@pytest.mark.parametrize("aggregator", ["mean", "max_pool"])
+def test_engine_data_parallel_two_ranks(dev, aggregator):
+    """(max_pool: the layer-0 "gather" starts with the pool Linear, which reads the weights — the
+    deferred Adam step of the previous batch has to be applied in front of it, not behind it.)"""
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
     port = 29600 + (os.getpid() % 300)
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, False, aggregator), nprocs=world, join=True)
     flat0, loss0, steps0 = out[0]
     flat1, loss1, steps1 = out[1]
     assert steps0 == steps1 == STEPS
@@ -96,7 +99,7 @@ def test_engine_data_parallel_two_ranks(dev):
     # single-process emulation: both ranks' gradients, averaged, one Adam step
     from graphsage_amd import ops
     from graphsage_amd.dist import batch_counter, shard_seeds
-    data, model, train = _setup()
+    data, model, train = _setup(aggregator)
     eng = _engine(data, model, dev, keep_grads=True)
     shards = [shard_seeds(train, r, world).to(dev) for r in range(world)]
     for b in range(STEPS):
@@ -111,6 +114,67 @@ def test_engine_data_parallel_two_ranks(dev):
         ops.adam_step(eng.flat, eng.grad, eng.exp_avg, eng.exp_avg_sq, eng._steps[:1], 1e-2,
                       grad_scale=1.0 / world)
     torch.testing.assert_close(eng.flat.cpu(), flat0, rtol=1e-4, atol=1e-6)
+
+
+def _rccl_one_rank_worker(rank, world, port, out, aggregator):
+    """One rank, backend nccl (= RCCL): the engine's collective branch — asynchronous all-reduce
+    on RCCL's stream, work.wait() on the main stream, deferred Adam, the host's run-ahead bound —
+    on the hardware backend, with no host synchronisation between the steps."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from graphsage_amd.dist import batch_counter
+    data, model, _ = _setup(aggregator)
+    seeds = torch.randint(0, 1500, (B * LONG_STEPS,), generator=torch.Generator().manual_seed(2)).to(dev)
+    import copy
+    res = {}
+    for name, kw in (("plain", {}), ("collective", dict(force_collective=True, process_group=dist.group.WORLD))):
+        eng = _engine(data, copy.deepcopy(model), dev, **kw)
+        eng.trace = []
+        d = eng.depth
+        for b in range(d):
+            eng.prefetch(seeds[b * B:(b + 1) * B], batch_counter(0, LONG_STEPS, b, 0, 1))
+        losses = []
+        for b in range(LONG_STEPS):
+            nxt = seeds[(b + d) * B:(b + d + 1) * B] if b + d < LONG_STEPS else None
+            loss = eng.pipelined_step(nxt, batch_counter(0, LONG_STEPS, b + d, 0, 1) if nxt is not None else None)
+            losses.append(loss.clone())
+        if name == "collective":
+            assert eng._pending.active           # the last Adam is deferred until flush()
+        eng.flush()
+        torch.cuda.synchronize()
+        res[name] = (eng.flat.cpu(), [float(x) for x in losses], int(eng.step_dev), list(eng.trace),
+                     eng.overlap_gather)
+    out[0] = res
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("aggregator", ["mean", "max_pool"])
+def test_engine_collective_branch_on_rccl_one_rank(dev, aggregator):
+    out = mp.Manager().dict()
+    port = 28300 + (os.getpid() % 300)
+    mp.spawn(_rccl_one_rank_worker, args=(1, port, out, aggregator), nprocs=1, join=True)
+    plain, coll = out[0]["plain"], out[0]["collective"]
+    assert plain[2] == coll[2] == LONG_STEPS
+    assert not coll[4]                                     # the collective selects the serial schedule
+    # same batches, same arithmetic (float atomics: last bits differ between any two runs)
+    torch.testing.assert_close(torch.tensor(coll[1]), torch.tensor(plain[1]), rtol=2e-4, atol=1e-5)
+    torch.testing.assert_close(coll[0], plain[0], rtol=2e-3, atol=2e-5)
+    assert sum(coll[1][-8:]) < sum(coll[1][:8])
+    # order in which a steady-state step is enqueued: the all-reduce is launched behind the
+    # backward, the next batch's weight-free layer-0 gather goes between that launch and the
+    # wait, Adam behind the wait, the forward contraction behind Adam.  (With a pooling
+    # aggregator the layer-0 "gather" reads the pool weights: wait and Adam come first.)
+    tr = coll[3]
+    first = tr.index("allreduce_launch")
+    steady = tr[first:]
+    per_step = (["allreduce_launch", "gather0", "allreduce_wait", "adam", "forward_backward"] if aggregator == "mean"
+                else ["allreduce_launch", "allreduce_wait", "adam", "gather0", "forward_backward"])
+    n = (len(steady) - 1) // len(per_step)
+    assert n >= LONG_STEPS - 2
+    assert steady[:n * len(per_step)] == per_step * n
 
 
 def _trainer_worker(rank, world, port, out):
