@@ -351,6 +351,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_coll = args.force_collective and world == 1
+    # RCCL prints a version banner on the process's stdout when its first communicator comes up:
+    # with a process group, everything that is not the result goes to stderr (fd level, so that
+    # native libraries are covered too) and rank 0 writes its ONE JSON line to the real stdout
+    result_fd = None
+    if world > 1 or force_coll:
+        sys.stdout.flush()
+        result_fd = os.dup(1)
+        os.dup2(2, 1)
     if force_coll:
         import socket
         with socket.socket() as s_:
@@ -648,7 +656,10 @@ def main():
             "variant": args.variant, "hip_graph": use_graph, "force_collective": bool(force_coll),
             "host_enqueue_ms_per_step": round(res["issued"] / args.steps * 1e3, 4), "overlap_gather": bool(overlapped),
         }
-        print(json.dumps(out), flush=True)
+        if result_fd is None:
+            print(json.dumps(out), flush=True)
+        else:
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or force_coll:
         torch.distributed.destroy_process_group()
 

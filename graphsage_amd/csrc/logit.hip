@@ -144,7 +144,11 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
                  int n, const int64_t* __restrict__ labels, const int64_t* __restrict__ label_rows,
                  float grad_scale, float* __restrict__ agg, int64_t ld_agg, float* __restrict__ y, int64_t ld_y,
                  float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
-                 float* __restrict__ row_loss, float* __restrict__ h_root, int64_t ld_h_root) {
+                 float* __restrict__ row_loss, float* __restrict__ h_root, int64_t ld_h_root,
+                 int64_t* __restrict__ pred) {
+  // Forward-only callers (sage_logit_layer_infer) pass labels = agg = dz = row_loss = NULL and
+  // take y and / or pred (the arg-max class of each seed row); every one of these tests is
+  // wave-uniform.
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kLogitWaves + threadIdx.x / kWave;
@@ -182,7 +186,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   const int64_t tc = live ? t : m - 1;                 // (dead waves of the last workgroup: clamped, results unused)
   const int64_t s0 = seg_ptr[tc];
   const int64_t len = seg_ptr[tc + 1] - s0;
-  const int64_t lab_row = label_rows != nullptr ? label_rows[tc] : tc;
+  const int64_t lab_row = (labels != nullptr && label_rows != nullptr) ? label_rows[tc] : tc;
   {
     const float4* rp = reinterpret_cast<const float4*>(hrows + tc * ld_h);
 #pragma unroll
@@ -195,7 +199,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   WeightStage st;                                      // requested behind it, stored while the rows travel
   st.init(nq);
   st.load(0, n, w_l, ld_wl, w_r, ld_wr);
-  const int64_t lab = labels[lab_row];                 // needs lab_row
+  const int64_t lab = labels != nullptr ? labels[lab_row] : -1;      // needs lab_row
   LOGIT_STAMP(0, 1);
   bool staged = false;
   if constexpr (PRE) {
@@ -267,10 +271,12 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
         acc[v].w /= cnt;
       }
     }
-    float4* ap = reinterpret_cast<float4*>(agg + t * ld_agg);
+    if (agg != nullptr) {
+      float4* ap = reinterpret_cast<float4*>(agg + t * ld_agg);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      if (in_row(v)) ap[lane + kWave * v] = acc[v];
+      for (int v = 0; v < NV; ++v) {
+        if (in_row(v)) ap[lane + kWave * v] = acc[v];
+      }
     }
   }
   if (!staged) st.store(wlds, 0, n, h);      // dead waves and seeds without neighbours
@@ -340,6 +346,16 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   const bool clamped = inv >= 1.f / kNormEps;
   const float yv = zc / denom;
   const float mx = wave_top(has ? yv : -INFINITY);
+  if (pred != nullptr) {
+    // torch.argmax's choice: the first class that attains the maximum
+    const unsigned long long at_max = __ballot(has && yv == mx);
+    if (lane == 0) pred[t] = at_max != 0ull ? static_cast<int64_t>(__builtin_ctzll(at_max)) : 0;
+  }
+  if (dz == nullptr) {       // forward only
+    if (lane == 0 && inv_norm != nullptr) inv_norm[t] = inv;
+    if (has && y != nullptr) y[t * ld_y + lane] = yv;
+    return;
+  }
   const float se = wave_total(has ? expf(yv - mx) : 0.f);
   const float lse = mx + logf(se);
   const float scale = grad_scale / static_cast<float>(m);
@@ -488,33 +504,24 @@ int allow_lds(K kernel, size_t bytes, const char* who) {
 
 using namespace sage;
 
-extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
-                                    sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
-                                    const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
-                                    const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
-                                    float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
-                                    float* row_loss, float* h_root, sage_i64 ld_h_root, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace {
+int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
+                     sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n,
+                     const sage_i64* labels, const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
+                     float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz, float* row_loss, float* h_root,
+                     sage_i64 ld_h_root, sage_i64* pred, hipStream_t stream) {
   size_t lds = 0;
-  const int rc = check_common("sage_logit_layer_fwd", m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
+  const int rc = check_common(who, m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
   if (rc != SAGE_OK) return rc;
-  SAGE_REQUIRE(h_rows && seg_ptr && src && labels && agg && dz && row_loss, SAGE_EINVAL,
-               "sage_logit_layer_fwd: NULL pointer argument");
-  SAGE_REQUIRE(ld_h >= h && ld_h % 4 == 0 && vec16(h_rows) && ld_agg >= h && ld_agg % 4 == 0 && vec16(agg) && ld_dz >= n &&
-                   (y == nullptr || ld_y >= n),
-               SAGE_EINVAL, "sage_logit_layer_fwd: rows of h / agg must be 16-byte aligned, ld_dz / ld_y >= n");
-  SAGE_REQUIRE(h_root == nullptr || (ld_h_root >= h && ld_h_root % 4 == 0 && vec16(h_root) && h_root != h_rows), SAGE_EINVAL,
-               "sage_logit_layer_fwd: rows of h_root must be 16-byte aligned and at least h wide, and not alias h_rows");
-  const bool pre = h_root != nullptr;
   const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
   const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
 #define SAGE_LOGIT_FWD_P(NV, FULL, PRE)                                                                         \
   do {                                                                                                      \
-    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE>, lds, "sage_logit_layer_fwd");                \
+    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE>, lds, who);                                   \
     if (rc2 != SAGE_OK) return rc2;                                                                         \
     logit_fwd_kernel<NV, FULL, PRE><<<grid, kLogitBlock, lds, stream>>>(                                    \
         h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, \
-        ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root);                                            \
+        ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, pred);                                      \
   } while (0)
 #define SAGE_LOGIT_FWD(NV, FULL)                                                                                \
   do {                                                                                                      \
@@ -532,6 +539,38 @@ extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sa
 #undef SAGE_LOGIT_FWD_P
   SAGE_CHECK_LAUNCH("logit_fwd_kernel");
   return SAGE_OK;
+}
+}  // namespace
+
+extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
+                                    sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                                    const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
+                                    const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
+                                    float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                                    float* row_loss, float* h_root, sage_i64 ld_h_root, void* stream_) {
+  SAGE_REQUIRE(h_rows && seg_ptr && src && labels && agg && dz && row_loss, SAGE_EINVAL,
+               "sage_logit_layer_fwd: NULL pointer argument");
+  SAGE_REQUIRE(ld_h >= 4 && ld_h % 4 == 0 && vec16(h_rows) && ld_agg >= h && ld_agg % 4 == 0 && vec16(agg) && ld_dz >= n &&
+                   (y == nullptr || ld_y >= n) && ld_h >= h,
+               SAGE_EINVAL, "sage_logit_layer_fwd: rows of h / agg must be 16-byte aligned, ld_dz / ld_y >= n");
+  SAGE_REQUIRE(h_root == nullptr || (ld_h_root >= h && ld_h_root % 4 == 0 && vec16(h_root) && h_root != h_rows), SAGE_EINVAL,
+               "sage_logit_layer_fwd: rows of h_root must be 16-byte aligned and at least h wide, and not alias h_rows");
+  return launch_logit_fwd("sage_logit_layer_fwd", h_root != nullptr, h_rows, ld_h, seg_ptr, src, m, h, reduce, w_l, ld_wl, w_r,
+                          ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y, inv_norm, dz, ld_dz, row_loss,
+                          h_root, ld_h_root, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int sage_logit_layer_infer(const float* h_rows, sage_i64 ld_h, int pre_activation, const sage_i64* seg_ptr,
+                                      const sage_i64* src, sage_i64 m, int h, int reduce, const float* w_l,
+                                      sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n, float* y, sage_i64 ld_y,
+                                      sage_i64* pred, void* stream_) {
+  SAGE_REQUIRE(h_rows && seg_ptr && src && (y || pred), SAGE_EINVAL,
+               "sage_logit_layer_infer: NULL pointer argument (one of y / pred is required)");
+  SAGE_REQUIRE(ld_h >= h && ld_h % 4 == 0 && vec16(h_rows) && (y == nullptr || ld_y >= n), SAGE_EINVAL,
+               "sage_logit_layer_infer: rows of h must be 16-byte aligned, ld_y >= n");
+  return launch_logit_fwd("sage_logit_layer_infer", pre_activation != 0, h_rows, ld_h, seg_ptr, src, m, h, reduce, w_l, ld_wl,
+                          w_r, ld_wr, n, nullptr, nullptr, 1.f, nullptr, 0, y, ld_y, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                          pred, static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,

@@ -299,6 +299,7 @@ class SageTrainEngine:
         # ahead of the device: it blocks on the event recorded that many steps ago
         self.run_ahead = 8
         self._dp_events = []
+        self._dp_ring = [torch.cuda.Event() for _ in range(3)]
         # pipelining state
         main = torch.cuda.current_stream(dev)
         self.side = new_side_stream(dev, [main])
@@ -815,13 +816,16 @@ class SageTrainEngine:
             self.ready[slot].record(self.side)
 
     def pipelined_step(self, next_seeds=None, next_counter=None, before_gather=None, after_gather=None,
-                       gather_events=None):
+                       gather_events=None, infer_pred=None):
         """Train on the oldest prefetched batch while the side stream prepares the following ones:
         the sampler of batch i+depth and, with overlap_gather, the layer-0 gather of batch i+1
         (held back until this step has started, so that it runs beside the forward GEMM).
         Measurement hooks for the layer-0 gather this call launches: before_gather / after_gather
         are called around it on its stream; gather_events = (start, stop) raw HIP event handles
-        are attached to the launch itself (gather_layer0)."""
+        are attached to the launch itself (gather_layer0).
+        infer_pred (int64[B] device tensor): forward only — the same pipeline (sampler ahead, layer-0
+        gather of the next batch beside this batch's contraction), no backward, no optimizer step;
+        the arg-max class of every seed row is written to infer_pred (evaluate())."""
         if self.n_pref == self.n_comp:
             raise RuntimeError("pipelined_step() needs a prefetch() first")
         i = self.n_comp
@@ -861,16 +865,24 @@ class SageTrainEngine:
         # stream while this step's sampler wait and (weight-free) layer-0 gather were enqueued;
         # its Adam step goes here, just before the first kernel that reads the weights
         self.flush()
-        self.forward_backward(slot=p, skip_gather0=True)
-        if self.collective:
+        if infer_pred is not None:
+            self._infer_batch(p, infer_pred)
+        else:
+            self.forward_backward(slot=p, skip_gather0=True)
+        if infer_pred is not None:
+            pass
+        elif self.collective:
             self._note('allreduce_launch')
             self._pending.launch(self.grad, self.pg, force=True)
-            # bound the host's run-ahead: with RCCL neither the launch nor wait() blocks the host
-            ev = torch.cuda.Event()
-            ev.record(main)
-            self._dp_events.append(ev)
-            if len(self._dp_events) > self.run_ahead:
-                self._dp_events.pop(0).synchronize()
+            # bound the host's run-ahead: with RCCL neither the launch nor wait() blocks the host.
+            # One event per run_ahead/2 steps, two in flight: the host is 4 to 8 steps ahead.
+            half = max(1, self.run_ahead // 2)
+            if (i + 1) % half == 0:
+                ev = self._dp_ring[(i // half) % 3]
+                ev.record(main)
+                self._dp_events.append(ev)
+                if len(self._dp_events) > 2:
+                    self._dp_events.pop(0).synchronize()
         else:
             self.optimizer_step()
         if (i + 1) % self.group == 0:
@@ -878,6 +890,49 @@ class SageTrainEngine:
             ev.record(main)
             self.cons_latest, self.cons_rec_seq = ev, i
         return self.loss
+
+    def _infer_batch(self, slot, pred):
+        """Forward of the batch in `slot` (its layer-0 aggregate is in place) down to the arg-max
+        class of every seed row (reference models/graphsage.py:51-68 + the argmax of
+        fig2a/runners/graphsage_runners.py:57-66).  Supervised mean / sum step: the layers below
+        the last as in training, then ONE launch for the class-logit layer (sage_logit_layer_infer:
+        reduce, both weight products, normalise, arg-max); recorded once per slot, replayed with
+        this batch's output pointer.  Everything else: the separate kernels + torch.argmax."""
+        self._note('infer')
+        self.last_slot = slot
+        B = self.B
+        if not (pred.is_cuda and pred.dtype == torch.int64 and pred.dim() == 1 and pred.is_contiguous()
+                and pred.numel() >= B):
+            raise RuntimeError("infer_pred must be a contiguous CUDA int64 vector of at least B elements")
+        if not self.fused_logit:
+            if self.unsup:
+                self.make_pos_neg(slot, self.slot_counter[slot])
+            self._taped('f1', slot, lambda: self._forward(slot, True))
+            torch.argmax(self.act[-1]['y'][:B], dim=1, out=pred[:B])
+            return
+        buf, last, layer, prev = self.bufs[slot], self.act[-1], self.model.layers[-1], self.act[-2]
+
+        def run():
+            # (the normalise pass of the hidden layer stays: it is what hands z back zeroed to the
+            # stream-K contraction of the next batch — or of the next TRAINING step)
+            self._forward_layers(slot, 0, True, upto=self.L - 1)
+            ops.logit_layer_infer(prev['h'], buf.seg_ptr, buf.src, B, self.reduce, layer.lin_l.weight,
+                                  layer.lin_r.weight, y=last['y'], pred=pred)
+        if not self.use_tapes:
+            run()
+            return
+        key = ('infer', slot, torch.cuda.current_stream().cuda_stream)
+        entry = self._tapes.get(key)
+        if entry is None:
+            with _lib.recording() as tape:
+                run()
+            fn, args, name = tape[-1]
+            self._tapes[key] = (list(tape[:-1]), fn, list(args), name)
+            return
+        head, fn, args, name = entry
+        _lib.replay(head)
+        args[15] = pred.data_ptr()           # sage_logit_layer_infer(..., pred, stream)
+        _lib.check(fn(*args), name)
 
     def flush(self):
         """Apply a deferred optimizer step.  Under data parallelism pipelined_step() returns with
@@ -924,53 +979,61 @@ class SageTrainEngine:
         return total / (nb * self.B + tail)
 
     @torch.no_grad()
-    def evaluate(self, seeds, counter0=1 << 40):
+    def evaluate(self, seeds, counter0=1 << 40, return_pred=False):
         """Forward-only pass over `seeds` (any length): returns (correct, count) as device int64
         tensors — accuracy = micro-F1 for single-label classification (what
         f1_score(average='micro') returns in trainers/node_level_graphsage_trainers.py:56-57).
-        Sampled fan-out neighbourhoods as in GraphSAGE.inference (models/graphsage.py:51-68)."""
+        Sampled fan-out neighbourhoods as in GraphSAGE.inference (models/graphsage.py:51-68).
+        Runs on the training pipeline (pipelined_step(infer_pred=...)): the sampler `depth`
+        batches ahead on its stream, with overlap_gather the layer-0 gather of batch b+1 beside
+        the contraction of batch b, call tapes, one launch for the class-logit layer, no torch op
+        per batch; the predictions are compared with the labels once, after the loop.
+        return_pred: also return the predicted classes (int64[len(seeds)])."""
         self._require_eager("evaluate()")
         if self.primed:
             raise RuntimeError("a prefetched batch is pending")
         self.flush()
-        self._main_touched = True
         B = self.B
         n = seeds.numel()
-        last = self.act[-1]
         nb = (n + B - 1) // B
-        pred_all = torch.empty(nb * B, dtype=torch.int64, device=self.dev)   # compared once, after the loop
-        # the sampler of batch b+1 runs on the sampler stream (two sample slots in turn) while
-        # batch b is forwarded: its ~95 us of latency-bound kernels are 40 % of a forward-only batch
-        main, side = torch.cuda.current_stream(), self.samp
-        sampled = [torch.cuda.Event(), torch.cuda.Event()]
-        consumed = [torch.cuda.Event(), torch.cuda.Event()]
-        side.wait_stream(main)
-
-        def issue(b):
-            chunk = seeds[b * B:(b + 1) * B]
-            valid = chunk.numel()
-            if valid < B:      # pad the tail with its first seed; the padded rows are not compared
-                chunk = torch.cat([chunk, chunk[:1].expand(B - valid)])
-                side.wait_stream(main)          # (the cat ran on the main stream)
-            chunk = chunk.contiguous()
-            chunk.record_stream(side)
-            if b >= 2:
-                side.wait_event(consumed[b & 1])
-            self.sample(chunk, counter0 + b, slot=b & 1, stream=side)
-            sampled[b & 1].record(side)
-
-        if nb:
-            issue(0)
+        pred_all = torch.empty(max(nb, 1) * B, dtype=torch.int64, device=self.dev)
+        if n < nb * B:      # pad the tail with its first seed; the padded rows are not compared
+            padded = torch.cat([seeds, seeds[(nb - 1) * B:(nb - 1) * B + 1].expand(nb * B - n)]).contiguous()
+        else:
+            padded = seeds.contiguous()
+        self._main_touched = True       # (the cat above ran on the main stream: prefetch() waits for it)
+        d = self.depth
+        for b in range(min(d, nb)):
+            self.prefetch(padded[b * B:(b + 1) * B], counter0 + b)
         for b in range(nb):
-            if b + 1 < nb:
-                issue(b + 1)
-            main.wait_event(sampled[b & 1])
-            self.forward(slot=b & 1)
-            torch.argmax(last['y'][:B], dim=1, out=pred_all[b * B:(b + 1) * B])
-            consumed[b & 1].record(main)
-        main.wait_stream(side)
+            nxt = padded[(b + d) * B:(b + d + 1) * B] if b + d < nb else None
+            self.pipelined_step(nxt, counter0 + b + d if nxt is not None else None,
+                                infer_pred=pred_all[b * B:(b + 1) * B])
         correct = (pred_all[:n] == self.labels[seeds]).sum().view(1)
-        return correct, torch.full((1,), n, dtype=torch.int64, device=self.dev)
+        count = torch.full((1,), n, dtype=torch.int64, device=self.dev)
+        if return_pred:
+            return correct, count, pred_all[:n]
+        return correct, count
+
+    def evaluate_loader(self, loader, return_pred=False):
+        """evaluate() on the seeds of an evaluation loader (graphsage_amd.samplers.UniformLoader),
+        with the Philox counters one pass over that loader would use — the sampled neighbourhoods
+        are the ones GraphSAGE.inference(loader) would see (models/graphsage.py:51-68) — and the
+        loader's epoch advanced by the TWO passes the reference makes per evaluation (inference,
+        then a second walk for the labels: trainers/node_level_graphsage_trainers.py:54-55,
+        fig2a/runners/graphsage_runners.py:60-62).  None when the loader's batches are not the
+        engine's (other batch size / fan-out / sampler seed / graph, shuffled or sharded seeds):
+        the caller then walks the loader itself."""
+        from .dist import batch_counter
+        samp = loader.neighbor_sampler
+        if (loader.batch_size != self.B or list(samp.num_neighbors) != self.fanout or samp.seed != self.rng_seed
+                or samp.graph is not self.graph or loader.shuffle or loader.world_size != 1 or loader.drop_last
+                or loader.transform is not None or len(loader.dataset) == 0):
+            return None
+        counter0 = batch_counter(loader.epoch, len(loader), 0, 0, 1)
+        out = self.evaluate(loader._idx_dev, counter0=counter0, return_pred=return_pred)
+        loader.epoch += 2
+        return out
 
     # ------------------------------------------------------------------ pipelined, HIP graphs
     def capture(self, seed_pool, counter0=0, counter_stride=1, split_gather=False):

@@ -78,10 +78,19 @@ def train(epoch, model, optimizer, train_loader, engine=None):
 
 
 @torch.no_grad()
-def test(model, subgraph_loader):
-    """Returns (accuracy, seconds for the full pass)."""
+def test(model, subgraph_loader, engine=None):
+    """Returns (accuracy, seconds for the full pass).  With an engine the pass runs on its
+    forward-only pipeline (engine.evaluate_loader: the same sampled neighbourhoods, arg-max on
+    the device); the timed part is the same — everything up to the predictions."""
     torch.cuda.synchronize()
     start = time.time()
+    if engine is not None:
+        model.eval()
+        out = engine.evaluate_loader(subgraph_loader)
+        if out is not None:
+            torch.cuda.synchronize()
+            test_time = time.time() - start
+            return int(out[0]) / int(out[1]), test_time
     y_hat = model.inference(subgraph_loader).argmax(dim=-1)
     torch.cuda.synchronize()
     test_time = time.time() - start
@@ -118,7 +127,7 @@ def run(aggregator, dataset=None, num_epochs=None, batch_size=BATCH_SIZE, k1=K1,
     loss = test_acc = None
     for epoch in range(1, num_epochs + 1):
         loss, epoch_train_time = train(epoch, model, optimizer, train_loader, engine)
-        test_acc, epoch_test_time = test(model, test_loader)
+        test_acc, epoch_test_time = test(model, test_loader, engine)
         if verbose:
             print(f'Epoch: {epoch:02d}, Loss: {loss:.4f}, Test Acc: {test_acc:.4f}')
         train_time += epoch_train_time

@@ -838,6 +838,30 @@ def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_row
     _lib.check(rc, "sage_logit_layer_fwd")
 
 
+def logit_layer_infer(h_rows, seg_ptr, src, m, reduce, w_l, w_r, y=None, pred=None, pre_activation=False):
+    """The last SAGE layer on the m seed rows, forward only (reference models/graphsage.py:51-68 +
+    the argmax of fig2a/runners/graphsage_runners.py:57-66): y [m, n] normalised logits and / or
+    pred int64[m] = argmax over the classes (first maximum, as torch.argmax).  Returns (y, pred)."""
+    lib = _lib.load()
+    hp, ld_h = _mat(h_rows, "h_rows")
+    wlp, ld_wl = _mat(w_l, "w_l")
+    wrp, ld_wr = _mat(w_r, "w_r")
+    n, h = w_l.shape
+    m = int(m)
+    if y is None and pred is None:
+        y = torch.empty((m, n), dtype=torch.float32, device=h_rows.device)
+    yp, ld_y = (None, 0) if y is None else _mat(y, "y")
+    if h_rows.size(1) != h or tuple(w_r.shape) != (n, h) or m <= 0 or h_rows.size(0) < m \
+            or seg_ptr.numel() < m + 1 or (y is not None and (y.size(0) < m or y.size(1) != n)) \
+            or (pred is not None and pred.numel() < m):
+        raise RuntimeError("logit_layer_infer: bad buffers")
+    rc = lib.sage_logit_layer_infer(hp, ld_h, 1 if pre_activation else 0, _vec(seg_ptr, torch.int64, "seg_ptr"),
+                                    _vec(src, torch.int64, "src"), m, h, REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n,
+                                    yp, ld_y, _vec(pred, torch.int64, "pred", allow_none=True), _stream())
+    _lib.check(rc, "sage_logit_layer_infer")
+    return y, pred
+
+
 def logit_layer_bwd(dz, seg_ptr, src, m, reduce, w_l, w_r, dh, row_loss=None, loss=None):
     """dh[src[e]] += (dz[t] @ w_l) (/ deg for mean), dh[t] += dz[t] @ w_r for the m seed rows, and
     loss = mean(row_loss[:m]) if both are given — one launch (sage_linear_dinput2 +

@@ -135,6 +135,13 @@ class SupervisedGraphSageTrainerForNodeLevelTask(SupervisedGraphSageBaseTrainer)
 
     @torch.no_grad()
     def eval(self, loader):
+        if self.engine is not None and not self.engine.unsup:
+            # the engine's forward-only pipeline over the same sampled neighbourhoods
+            self.model.eval()
+            out = self.engine.evaluate_loader(loader)
+            if out is not None:
+                acc = int(out[0]) / int(out[1])
+                return acc, acc
         y_hat = self.model.inference(loader).argmax(dim=-1)
         y = torch.cat([batch.y[:batch.batch_size] for batch in loader]).to(y_hat.device)
         acc = float(_micro_f1(y_hat, y))

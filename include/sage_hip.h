@@ -471,6 +471,19 @@ int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_pt
                          sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
                          const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,
                          const float* row_loss, float* loss, void* stream);
+/* The same layer forward-only, for the inference pass (GraphSAGE.inference,
+ * models/graphsage.py:51-68, and the `y_hat.argmax(dim=-1)` of the runners' test(),
+ * fig2a/runners/graphsage_runners.py:57-66 / trainers/node_level_graphsage_trainers.py:56):
+ *   y[t]    = normalised logits of seed row t as above (optional),
+ *   pred[t] = the first class attaining max_c y[t, c] — torch.argmax's choice (optional; one of
+ *             y / pred is required).
+ * No labels, loss, gradient or kept aggregate.  pre_activation != 0: h_rows holds the previous
+ * layer's pre-activation rows, normalised and rectified on their way in (sage_logit_layer_fwd's
+ * h_root mode without the stored seed rows).  Same shape limits (SAGE_ELIMIT). */
+int sage_logit_layer_infer(const float* h_rows, sage_i64 ld_h, int pre_activation, const sage_i64* seg_ptr,
+                           const sage_i64* src, sage_i64 m, int h, int reduce, const float* w_l,
+                           sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n, float* y, sage_i64 ld_y,
+                           sage_i64* pred, void* stream);
 
 /* (f-2) unsupervised loss of trainers/base_trainers.py:179-181 on m rows of width n:
  *   loss[0] = -mean logsigmoid(<out_i, pos_i>) - mean logsigmoid(-<out_i, neg_i>)

@@ -127,3 +127,55 @@ def test_pipelined_eager_matches_serial_steps(dev, overlap):
     torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
     assert torch.equal(serial.state_sum, piped.state_sum)
     piped.step(pool[:B], counter=99)          # pipeline drained: serial stepping works again
+
+
+@pytest.mark.parametrize("aggregator,overlap", [("mean", False), ("mean", True), ("sum", True), ("max", False),
+                                                ("max_pool", False)])
+def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap):
+    """engine.evaluate() — the training pipeline run forward-only, one launch for the class-logit
+    layer of the mean / sum step — predicts what GraphSAGE.inference + argmax predict
+    (reference models/graphsage.py:51-68, fig2a/runners/graphsage_runners.py:57-66) on the same
+    sampled batches; the tail that does not fill a batch included, and a training step afterwards
+    still finds its accumulation buffers zeroed."""
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler, UniformLoader
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = planted_partition(3000, 60000, 40, 6, seed=2)
+    B = 64
+    n_eval = 5 * B + 17
+    ids = torch.randperm(3000, generator=torch.Generator().manual_seed(3))[:n_eval]
+    torch.manual_seed(0)
+    model = GraphSAGE(40, 32, aggregator, 2, 6).to(dev)
+    graph = device_graph(data)
+    engine = SageTrainEngine(copy.deepcopy(model), NeighborSampler(data, [5, 3], seed=7), graph.features(data),
+                             graph.labels(data), B, lr=1e-2, overlap_gather=overlap)
+    ref_engine = SageTrainEngine(copy.deepcopy(model), NeighborSampler(data, [5, 3], seed=7), graph.features(data),
+                                 graph.labels(data), B, lr=1e-2)
+    # a few training steps first: evaluate() must cope with a used pipeline and leave it usable
+    train = torch.arange(4 * B, device=dev)
+    for eng in (engine, ref_engine):
+        eng.train_epoch(train, epoch=0)
+    for _ in range(2):
+        correct, count, pred = engine.evaluate(ids.to(dev), counter0=900, return_pred=True)
+        assert int(count) == n_eval and pred.numel() == n_eval
+        # the same batches through the separate kernels of forward() + torch.argmax
+        want, margin = [], []
+        padded = torch.cat([ids, ids[5 * B:5 * B + 1].expand(6 * B - n_eval)]).to(dev)
+        for b in range(6):
+            ref_engine.sample(padded[b * B:(b + 1) * B].contiguous(), 900 + b, slot=0)
+            ref_engine.forward(slot=0)
+            y = ref_engine.act[-1]['y'][:B]
+            top = y.topk(2, dim=1).values
+            want.append(y.argmax(dim=1))
+            margin.append(top[:, 0] - top[:, 1])
+        want, margin = torch.cat(want)[:n_eval], torch.cat(margin)[:n_eval]
+        differ = pred != want
+        assert not bool((differ & (margin > 1e-5)).any())      # only numerical ties may flip
+        assert int(differ.sum()) <= 2
+        assert int(correct) == int((pred == graph.labels(data)[ids.to(dev)]).sum())
+        # ... and training goes on as if nothing had happened in between
+        for eng in (engine, ref_engine):
+            eng.train_epoch(train, epoch=1)
+        torch.testing.assert_close(engine.flat, ref_engine.flat, rtol=1e-4, atol=1e-6)

@@ -750,3 +750,45 @@ def test_logit_layer_rejects_weights_beyond_lds(dev):
     with pytest.raises(RuntimeError, match="do not fit"):
         ops.logit_layer_fwd(z, seg, seg, 8, "mean", w, w, seg, None, torch.zeros(8, 512, device=dev), None, None,
                             torch.zeros(8, 64, device=dev), torch.zeros(8, device=dev))
+
+
+@pytest.mark.parametrize("h,n,pre", [(256, 41, False), (256, 41, True), (64, 7, False), (512, 37, True), (100, 5, False)])
+def test_logit_layer_infer_matches_torch(dev, h, n, pre):
+    """sage_logit_layer_infer (forward-only class-logit layer, reference layers/sage.py:99-134 on
+    the seed rows + argmax) against plain torch: y within 2e-5, pred = first arg-max of y."""
+    import torch.nn.functional as F
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(h + n)
+    rows, m = 700, 150
+    x = ops.empty_rows(rows, h, dev)
+    x.copy_(torch.randn(rows, h, generator=g))
+    deg = torch.randint(0, 12, (m,), generator=g)
+    deg[3] = 0
+    deg[7] = 70                         # more than one wave of neighbour ids
+    seg = torch.zeros(m + 1, dtype=torch.int64)
+    seg[1:] = deg.cumsum(0)
+    src = torch.randint(0, rows, (int(seg[-1]),), generator=g)
+    wl = ops.empty_rows(n, h, dev)
+    wr = ops.empty_rows(n, h, dev)
+    wl.copy_(torch.randn(n, h, generator=g) / h ** 0.5)
+    wr.copy_(torch.randn(n, h, generator=g) / h ** 0.5)
+    for reduce in ("mean", "sum"):
+        y = torch.zeros(m, n, device=dev)
+        pred = torch.full((m,), -1, dtype=torch.int64, device=dev)
+        ops.logit_layer_infer(x, seg.to(dev), src.to(dev), m, reduce, wl, wr, y=y, pred=pred, pre_activation=pre)
+        xr = x.double().cpu()
+        if pre:
+            xr = F.relu(F.normalize(xr, dim=-1))
+        agg = torch.zeros(m, h, dtype=torch.float64)
+        dst = torch.repeat_interleave(torch.arange(m), deg)
+        agg.index_add_(0, dst, xr[src])
+        if reduce == "mean":
+            agg /= deg.clamp(min=1).unsqueeze(1).double()
+        z = agg @ wl.double().cpu().T + xr[:m] @ wr.double().cpu().T
+        want = F.normalize(z, dim=-1)
+        torch.testing.assert_close(y.cpu().double(), want, rtol=1e-4, atol=2e-5)
+        assert torch.equal(pred, y.argmax(dim=1))
+        # pred alone (the evaluation pass does not keep y)
+        pred2 = torch.full((m,), -1, dtype=torch.int64, device=dev)
+        ops.logit_layer_infer(x, seg.to(dev), src.to(dev), m, reduce, wl, wr, pred=pred2, pre_activation=pre)
+        assert torch.equal(pred2, pred)
