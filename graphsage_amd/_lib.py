@@ -28,6 +28,7 @@ SIGNATURES = {
     "sage_sample_fanout_static": (c_int, [_P, _P, c_int64, _P, c_int, ctypes.POINTER(c_int), c_int,
                                           c_uint64, c_uint64, _P, c_uint32, c_int64, c_int64,
                                           _P, _P, _P, _P, _P, _P, _P]),
+    "sage_debug_exchange_wait": (c_int, [_P, c_int, _P, c_int, _P, _P]),
     "sage_ctrl_advance": (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P]),
     "sage_state_accumulate": (c_int, [_P, _P, _P]),
     "sage_random_nodes": (c_int, [c_int64, c_int64, c_uint64, c_uint64, _P, _P]),

@@ -56,17 +56,31 @@ __device__ inline void publish_total(unsigned long long* word, uint32_t total) {
   __hip_atomic_store(word, kReady | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// sum of the totals published under tickets 0 .. L-1, by one wave (every lane returns the sum)
-__device__ inline uint32_t sum_lower_tickets(unsigned long long* words, int L, int lane) {
+// sum of the totals published under tickets 0 .. L-1, by one wave (every lane returns the sum).
+// The wait is BOUNDED: the ticket argument (every lower ticket belongs to a workgroup that is
+// already resident and publishes before it waits) makes it short — microseconds — but it rests on
+// that workgroup making progress; a lane that has polled one word `poll_limit` times (the default
+// is of the order of a second) gives up, reports SAGE_ST_ERROR bit 4 and returns what it has, so
+// that a broken assumption ends as an error code of the call and not as a grid that never drains.
+// What follows then runs on a wrong prefix: every store of the hop kernels is bounds-checked
+// against the capacities, so the result is wrong but in bounds, and the error bit says so.
+constexpr int kPollLimit = 1 << 20;
+__device__ inline uint32_t sum_lower_tickets(unsigned long long* words, int L, int lane, int64_t* state,
+                                             int poll_limit) {
   uint32_t sum = 0;
+  bool gave_up = false;
   for (int j = lane; j < L; j += kWave) {
-    unsigned long long v;
-    for (;;) {
-      v = __hip_atomic_load(words + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((v & kReady) != 0) break;
+    unsigned long long v = __hip_atomic_load(words + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int polls = 0; (v & kReady) == 0 && !gave_up; ++polls) {
+      if (polls >= poll_limit) {
+        gave_up = true;
+        atomicOr(reinterpret_cast<unsigned long long*>(&state[SAGE_ST_ERROR]), 16ull);
+        break;
+      }
       __builtin_amdgcn_s_sleep(8);     // leave the issue slots and the L2 to the waves that compute
+      v = __hip_atomic_load(words + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    sum += static_cast<uint32_t>(v);
+    if ((v & kReady) != 0) sum += static_cast<uint32_t>(v);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -217,7 +231,7 @@ hop_sample_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict_
                   int fanout, int fcap, int hop, uint32_t seed_lo, uint32_t seed_hi,
                   uint64_t* __restrict__ table, int64_t edge_cap, int64_t* __restrict__ src,
                   int64_t* __restrict__ dst, int64_t* __restrict__ eid, int64_t* __restrict__ seg_ptr,
-                  int64_t* __restrict__ state) {
+                  int64_t* __restrict__ state, int poll_limit) {
   constexpr int NPB = kHopBlock / G;          // nodes per workgroup (16, 32 or 64: at most one wave's worth)
   __shared__ uint32_t sh_chosen[BIG ? kHopWaves * kMaxFanout : 1];
   __shared__ int s_L, s_cnt[NPB], s_off[NPB], s_total;
@@ -268,7 +282,7 @@ hop_sample_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict_
       s_total = total;
       publish_total(totals + L, static_cast<uint32_t>(total));
     }
-    const uint32_t base = sum_lower_tickets(totals, L, lane);
+    const uint32_t base = sum_lower_tickets(totals, L, lane, state, poll_limit);
     if (lane == 0) s_base = base;
   }
   __syncthreads();
@@ -305,7 +319,7 @@ __global__ void __launch_bounds__(kHopBlock)
 hop_flag_kernel(const int64_t* __restrict__ hopinfo_c,
                 unsigned long long* __restrict__ ticket, unsigned long long* __restrict__ totals,
                 int64_t node_cap, uint64_t* __restrict__ table, const int64_t* __restrict__ src,
-                int64_t* __restrict__ node, int hop, int64_t* __restrict__ state) {
+                int64_t* __restrict__ node, int hop, int64_t* __restrict__ state, int poll_limit) {
   __shared__ int s_L;
   __shared__ uint32_t s_wave[kHopWaves], s_base;
   const int lane = threadIdx.x & (kWave - 1);
@@ -339,7 +353,7 @@ hop_flag_kernel(const int64_t* __restrict__ hopinfo_c,
   }
   if (wave == 0) {
     if (lane == 0) publish_total(totals + L, total);
-    const uint32_t base = sum_lower_tickets(totals, L, lane);
+    const uint32_t base = sum_lower_tickets(totals, L, lane, state, poll_limit);
     if (lane == 0) s_base = base;
   }
   __syncthreads();
@@ -546,7 +560,7 @@ extern "C" int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* r
 #define SAGE_HOP_SAMPLE(GG, BB)                                                                       \
   hop_sample_kernel<GG, BB><<<grid, kHopBlock, 0, stream>>>(                                            \
       colptr, row, num_nodes, node, hopinfo, ticket_a, totals_a, k, static_cast<int>(fcap), h, seed_lo, \
-      seed_hi, relabel_table, edge_cap, src, dst, eid, seg_ptr, state)
+      seed_hi, relabel_table, edge_cap, src, dst, eid, seg_ptr, state, kPollLimit)
       if (k > kWave) SAGE_HOP_SAMPLE(64, true);
       else if (G == 64) SAGE_HOP_SAMPLE(64, false);
       else if (G == 32) SAGE_HOP_SAMPLE(32, false);
@@ -555,7 +569,7 @@ extern "C" int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* r
       SAGE_CHECK_LAUNCH("hop_sample_kernel");
     }
     hop_flag_kernel<<<static_cast<int>(cdiv(ecap > 0 ? ecap : 1, kHopBlock)), kHopBlock, 0, stream>>>(   // <= n_b
-        hopinfo, ticket_b, totals_b, node_cap, relabel_table, src, node, h, state);
+        hopinfo, ticket_b, totals_b, node_cap, relabel_table, src, node, h, state, kPollLimit);
     SAGE_CHECK_LAUNCH("hop_flag_kernel");
     {
       int64_t work = ecap;
@@ -643,6 +657,26 @@ extern "C" int sage_state_accumulate(const sage_i64* state, sage_i64* sum, void*
   SAGE_REQUIRE(state != nullptr && sum != nullptr, SAGE_EINVAL, "sage_state_accumulate: NULL pointer argument");
   state_accumulate_kernel<<<1, SAGE_STATE_WORDS, 0, static_cast<hipStream_t>(stream)>>>(state, sum);
   SAGE_CHECK_LAUNCH("state_accumulate_kernel");
+  return SAGE_OK;
+}
+
+namespace {
+// One wave of hop_flag_kernel's exchange on a prepared totals array (sage_debug_exchange_wait).
+__global__ void exchange_wait_kernel(unsigned long long* words, int L, int64_t* state, int poll_limit,
+                                     unsigned long long* out) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const uint32_t base = sum_lower_tickets(words, L, lane, state, poll_limit);
+  if (lane == 0) out[0] = base;
+}
+}  // namespace
+
+extern "C" int sage_debug_exchange_wait(unsigned long long* words, int num_words, sage_i64* state, int poll_limit,
+                                        unsigned long long* sum_out, void* stream) {
+  SAGE_REQUIRE(words && state && sum_out && num_words >= 0 && num_words <= 4096 && poll_limit >= 0 &&
+                   poll_limit <= kPollLimit,
+               SAGE_EINVAL, "sage_debug_exchange_wait: bad argument");
+  exchange_wait_kernel<<<1, kWave, 0, static_cast<hipStream_t>(stream)>>>(words, num_words, state, poll_limit, sum_out);
+  SAGE_CHECK_LAUNCH("exchange_wait_kernel");
   return SAGE_OK;
 }
 

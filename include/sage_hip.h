@@ -63,7 +63,10 @@ typedef int64_t sage_i64;
 #define SAGE_ST_EDGES 1      /* number of sampled edges so far                           */
 #define SAGE_ST_FRONT_BEGIN 2 /* local id range of the nodes the next hop expands       */
 #define SAGE_ST_FRONT_END 3
-#define SAGE_ST_ERROR 4      /* bit0: node capacity exceeded, bit1: edge capacity        */
+#define SAGE_ST_ERROR 4      /* bit0: node capacity exceeded, bit1: edge capacity,       */
+                             /* bit2: a seed is not a node, bit3: a CSC row id is not a  */
+                             /* node, bit4: the in-launch prefix exchange gave up        */
+                             /* waiting for another workgroup (result wrong, in bounds)  */
 #define SAGE_ST_HOP_NODES 8  /* [8+h]  = #nodes after hop h (h=0: the seeds)             */
 #define SAGE_ST_HOP_EDGES 24 /* [24+h] = #edges after hop h (h=0: 0)                     */
 #define SAGE_STATE_WORDS 40
@@ -142,6 +145,13 @@ int sage_sample_fanout_ctrl(const sage_i64* colptr, const sage_i64* row, sage_i6
                             sage_i64 edge_cap, sage_i64* node, sage_i64* src, sage_i64* dst,
                             sage_i64* eid, sage_i64* seg_ptr, sage_i64* state, void* workspace,
                             size_t workspace_bytes, void* stream);
+/* Diagnostic (tests only; no counterpart in the reference): ONE wave runs the sampler's bounded
+ * wait — the sum of the totals published in words[0 .. num_words) as {bit 63 = ready, low 32 bits
+ * = total} — with `poll_limit` polls per word instead of the sampler's own limit.  Words whose
+ * ready bit never appears are skipped after the limit and bit4 is set in state[SAGE_ST_ERROR];
+ * sum_out[0] receives the sum of the words that were ready. */
+int sage_debug_exchange_wait(unsigned long long* words, int num_words, sage_i64* state, int poll_limit,
+                             unsigned long long* sum_out, void* stream);
 int sage_ctrl_advance(sage_i64* ctrl_dev, sage_i64 d_counter, sage_i64 d_stamp, sage_i64 d_offset,
                       sage_i64 offset_wrap, void* stream);
 
@@ -256,16 +266,29 @@ int sage_coo_to_csr(const sage_i64* edge_src, const sage_i64* edge_dst, sage_i64
  *                 (+ bias[n]) (relu)
  * r1/r2: optional row maps (NULL = identity) so the root term can be read straight from
  * the global feature table through the batch's `node` vector.  a2/w2 may be NULL
- * (k2 = 0: 'gcn' aggregator / root_weight=False / pool).  Exact fp32 arithmetic on the
- * matrix cores (v_mfma_f32_32x32x2_f32): each output is an fp32 fma chain over k.
+ * (k2 = 0: 'gcn' aggregator / root_weight=False / pool).
  * Alignment: every pointer and row stride must be a multiple of 8 bytes.
- * Opt-in mode, environment variable SAGE_GEMM_X3=1 (read at every call; off by default):
- * large contractions (n > 64, 16-byte aligned operands, epilogue NONE / ACCUM) run on the
- * bf16 MFMA with every fp32 operand split into three bf16 terms (x = hi + mid + lo exactly)
- * and six cross products accumulated in fp32 — the error against an exact result is that of
- * the fp32 path or smaller, the bits are not those of an fp32 fma chain, and an Inf operand
- * gives NaN.  The same switch covers the large weight-gradient contractions of
- * sage_linear_dweight / sage_linear_dweight2 below.  No counterpart in the reference.
+ * Arithmetic — two kernels, chosen per call by the shape:
+ *   * LARGE contractions run in "bf16x3" mode BY DEFAULT: n > 64, every operand 16-byte
+ *     aligned (pointers and row strides), and at least 6 K-steps of 32 per workgroup slot of the
+ *     chip (about 1 GFLOP on MI355X); epilogues NONE, ACCUM, and BIAS / RELU on whole tiles.
+ *     Every fp32 operand is split round-to-nearest into three bf16 terms (x = hi + mid + lo
+ *     exactly) while it is staged, six of the nine cross products go through the bf16 MFMA
+ *     (v_mfma_f32_16x16x32_bf16) into fp32 accumulators; the three dropped products are
+ *     <= 2^-24 of the product.  The error against an exact result is that of an fp32 fma chain
+ *     on the same operands or smaller; the BITS are not those of an fp32 fma chain.  Domain:
+ *     an Inf operand gives NaN (Inf - Inf in the residuals) in every output it reaches, a NaN
+ *     operand NaN — the same outputs the fp32 kernel makes non-finite; operands below about
+ *     2^-110 lose their mid / lo terms to bf16 underflow (absolute error below 2^-126 per
+ *     product: invisible next to any normal-sized term of the same sum).
+ *     SAGE_GEMM_X3=0 in the environment (read at every call) switches the mode off.
+ *   * everything else — and every call under SAGE_GEMM_X3=0 — runs exact fp32 arithmetic on
+ *     the matrix cores (v_mfma_f32_32x32x2_f32): each output is an fp32 fma chain over k.
+ * Few-tile shapes take a stream-K / split-K schedule whose partial tiles are added with fp32
+ * atomics (summation order varies between runs; out must then hold zeros or the addend:
+ * SAGE_EPI_ACCUM).  The same routing covers the large weight-gradient contractions of
+ * sage_linear_dweight (with dbias) / sage_linear_dweight2 below (k > 64, m >= 2048 rows,
+ * 16-byte aligned operands).  No counterpart in the reference.
  * ---------------------------------------------------------------------------------- */
 int sage_linear_concat_fwd(const float* a1, sage_i64 ld_a1, const sage_i64* rows1, int k1,
                            const float* w1, sage_i64 ld_w1, const float* a2, sage_i64 ld_a2,

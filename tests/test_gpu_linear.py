@@ -792,3 +792,79 @@ def test_logit_layer_infer_matches_torch(dev, h, n, pre):
         pred2 = torch.full((m,), -1, dtype=torch.int64, device=dev)
         ops.logit_layer_infer(x, seg.to(dev), src.to(dev), m, reduce, wl, wr, pred=pred2, pre_activation=pre)
         assert torch.equal(pred2, pred)
+
+
+def test_bf16x3_mode_edges_of_its_domain(dev, monkeypatch):
+    """The default (bf16x3) contraction at the edges of its domain, against the exact-fp32 MFMA
+    kernel and float64 (include/sage_hip.h, sage_linear_concat_fwd):
+      * tiny operands (scaled by 2^-60 each: products near 2^-120, mid / lo terms of the split in
+        or below bf16's subnormal range) — relative to the largest output the error stays within
+        2x the fp32 kernel's;
+      * an Inf row and a NaN row in A: non-finite outputs in exactly the rows where the fp32
+        kernel's are non-finite, every other row untouched."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(77)
+    m, n, k = 13100, 256, 602
+    a, w = _rand((m, k), g), _rand((n, k), g, k ** -0.5)
+
+    def run(a_, w_, x3):
+        if x3:
+            monkeypatch.delenv("SAGE_GEMM_X3", raising=False)
+        else:
+            monkeypatch.setenv("SAGE_GEMM_X3", "0")
+        out = torch.full((m, n), 7.0, device=dev)
+        ops.linear_concat_fwd(_pad16(a_, dev), _pad16(w_, dev), out=out)
+        return out.cpu()
+    s = 2.0 ** -60
+    want = (a.double() * s) @ (w.double() * s).t()
+    f32, x3 = run(a * s, w * s, False), run(a * s, w * s, True)
+    top = float(want.abs().max())
+    assert top > 0 and top < 2.0 ** -100
+    e_f32, e_x3 = float((f32.double() - want).abs().max()) / top, float((x3.double() - want).abs().max()) / top
+    assert e_x3 <= 2.0 * e_f32 + 1e-7, (e_x3, e_f32)
+    assert not torch.equal(x3, f32)                       # the mode was really taken
+    bad = a.clone()
+    bad[5, 17] = float("inf")
+    bad[9000, 600] = float("nan")
+    bad[13099, 0] = float("-inf")
+    f32, x3 = run(bad, w, False), run(bad, w, True)
+    nf_f32, nf_x3 = ~torch.isfinite(f32).all(dim=1), ~torch.isfinite(x3).all(dim=1)
+    assert nf_f32.nonzero().view(-1).tolist() == [5, 9000, 13099]
+    assert torch.equal(nf_x3, nf_f32)
+    assert bool((~torch.isfinite(x3[[5, 9000, 13099]])).all())      # every output the bad operand reaches
+    good = ~nf_f32
+    want = a.double() @ w.double().t()
+    assert float((x3[good].double() - want[good]).abs().max()) <= 2.0 * float((f32[good].double() - want[good]).abs().max()) + 1e-7
+
+
+@pytest.mark.parametrize("m,n,relu", [(700, 256, True), (300, 64, True), (129, 100, False), (40, 512, True)])
+def test_l2norm_relu_bwd_z_matches_autograd(dev, m, n, relu):
+    """sage_l2norm_relu_bwd_z — the gradient of relu(normalize(z)) taken from the pre-activation
+    rows themselves (models/graphsage.py:47-48 + layers/sage.py:131-132 differentiated) — against
+    torch.autograd on the same z and upstream gradient, in float64; z (and dh) come back zeroed;
+    a zero row takes the clamp's gradient path (dz = g / eps)."""
+    import torch.nn.functional as F
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m + n)
+    z = torch.randn(m, n, generator=g)
+    z[3] = 0.0
+    z[7] *= 1e-3
+    dh = torch.randn(m, n, generator=g)
+    zr = z.double().clone().requires_grad_(True)
+    y = F.normalize(zr, dim=-1)
+    (F.relu(y) if relu else y).backward(dh.double())
+    want = zr.grad
+    z_dev, dh_dev = ops.empty_rows(m, n, dev), ops.empty_rows(m, n, dev)
+    z_dev.copy_(z)
+    dh_dev.copy_(dh)
+    m_dev = torch.tensor([m - 5], device=dev)
+    dz = torch.full((m, n), 9.0, device=dev)
+    ops.l2norm_relu_bwd_z(dh_dev, z_dev, relu, m=m, m_dev=m_dev, dz=dz, clear_dh=True)
+    live = m - 5
+    rows = [r for r in range(live) if r != 3]
+    torch.testing.assert_close(dz[rows].double().cpu(), want[rows], rtol=2e-4, atol=1e-5)
+    # the zero row: y = 0, dz = g * (1 / eps) with g = dh masked by y > 0 (all masked under relu)
+    ref3 = torch.zeros(n, dtype=torch.float64) if relu else dh[3].double() * 1e12
+    torch.testing.assert_close(dz[3].double().cpu(), ref3, rtol=1e-5, atol=0)
+    assert bool((z_dev[:live] == 0).all()) and bool((dh_dev[:live] == 0).all())
+    assert torch.equal(z_dev[live:].cpu(), z[live:]) and bool((dz[live:] == 9.0).all())   # beyond the device count: untouched

@@ -182,3 +182,32 @@ def test_random_nodes_and_bounded_random_neighbor(dev):
     bad[6] = 300
     ops.random_neighbor(colptr, row, bad, 4, 6, out=out, checked=False, num_dev=torch.tensor([123], device=dev))
     assert int(out[5]) == 0 and int(out[6]) == 0 and int(out[7]) == int(want[7])
+
+
+def test_exchange_wait_gives_up_with_an_error_bit(dev):
+    """The sampler's in-launch prefix exchange waits for totals that other workgroups publish; the
+    wait is bounded and ends in SAGE_ST_ERROR bit 4 instead of a grid that never drains.  Unit
+    harness (sage_debug_exchange_wait): one wave over a prepared totals array in which one word's
+    ready bit is never set."""
+    import ctypes
+    from graphsage_amd import _lib, ops
+    lib = _lib.load()
+    ready = 1 << 63
+    vals = [ready | 5, ready | 7, 0, ready | 11] + [ready | 1] * 100       # word 2 is never published
+    words = torch.tensor([v - (1 << 64) if v >= (1 << 63) else v for v in vals], dtype=torch.int64, device=dev)
+    state = torch.zeros(ops.STATE_WORDS, dtype=torch.int64, device=dev)
+    out = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.sage_debug_exchange_wait(ctypes.c_void_p(words.data_ptr()), len(vals), ctypes.c_void_p(state.data_ptr()),
+                                      2000, ctypes.c_void_p(out.data_ptr()), stream)
+    _lib.check(rc, "sage_debug_exchange_wait")
+    torch.cuda.synchronize()
+    assert int(state[ops.ST_ERROR]) == 16
+    assert int(out) == 5 + 7 + 11 + 100                    # what was ready
+    # every word ready: no error, the full sum
+    words[2] = words[0]
+    state.zero_()
+    rc = lib.sage_debug_exchange_wait(ctypes.c_void_p(words.data_ptr()), len(vals), ctypes.c_void_p(state.data_ptr()),
+                                      2000, ctypes.c_void_p(out.data_ptr()), stream)
+    _lib.check(rc, "sage_debug_exchange_wait")
+    assert int(state[ops.ST_ERROR]) == 0 and int(out) == 5 + 7 + 5 + 11 + 100
