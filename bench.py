@@ -395,7 +395,8 @@ def main():
     if args.aggregator == "lstm":
         settings.LSTM_NUM_INPUTS = args.lstm_num_inputs
     model = GraphSAGE(Fdim, args.hidden, args.aggregator, len(K), C).to(dev)
-    pooling = args.aggregator in ("max_pool", "mean_pool")
+    # (the aggregators whose dominant kernels are contractions: MFMA roofline instead of the gather's)
+    pooling = args.aggregator in ("max_pool", "mean_pool", "lstm")
     on_engine = (args.aggregator in _REDUCE and args.variant != "trainer-module"
                  and not (pooling and (args.module_path or args.variant != "fig2a")))
     if not on_engine and args.variant == "fig2a":
@@ -636,7 +637,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-shaped synthetic: N={N} E={E} F={Fdim} C={C}, "
-                                   f"B={B}/GPU, fan-out {K}, hidden {args.hidden}, aggregator {args.aggregator}, "
+                                   f"B={B}/GPU, fan-out {K}, hidden {args.hidden}, aggregator {args.aggregator}"
+                                   + (f" (LSTM_NUM_INPUTS {args.lstm_num_inputs})" if args.aggregator == "lstm" else "") + ", "
                                    f"Adam lr {args.lr}, " + {"fig2a": "fig2a step (supervised term only)",
                                                        "unsup": "UNSUPERVISED trainer step (random-walk loss, 3 forwards)"}.get(
                                        args.variant, "TRAINER step (supervised + unsupervised term, 3 forwards)"),

@@ -42,32 +42,47 @@ __global__ void segment_slots_kernel(const int64_t* __restrict__ seg_ptr,
 __device__ inline float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 
 // gates [m, 4F] in torch's (i, f, g, o) order; zero initial state: c = s(i)*tanh(g), h = s(o)*tanh(c)
+// bias_a / bias_b (optional, [4F] each): added to the gates on the way in (b_ih + b_hh of the
+// cell, when the contraction that produced `gates` ran without a bias epilogue)
+__device__ inline float gate_bias(const float* __restrict__ a, const float* __restrict__ b, int c) {
+  return (a != nullptr ? a[c] : 0.f) + (b != nullptr ? b[c] : 0.f);
+}
+
 __global__ void lstm_cell0_fwd_kernel(const float* __restrict__ gates, int64_t ld_g,
-                                      const float* __restrict__ nonempty, int64_t m, int F,
+                                      const float* __restrict__ nonempty, int64_t m,
+                                      const int64_t* __restrict__ m_dev, int F,
+                                      const float* __restrict__ bias_a, const float* __restrict__ bias_b,
                                       float* __restrict__ h, int64_t ld_h) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= m * F) return;
+  if (i >= dev_count(m_dev, m) * F) return;
   const int64_t r = i / F;
   const int f = static_cast<int>(i - r * F);
   const float* g = gates + r * ld_g;
-  const float c = sigmoidf(g[f]) * tanhf(g[2 * F + f]);
-  const float out = sigmoidf(g[3 * F + f]) * tanhf(c);
+  const float gi = g[f] + gate_bias(bias_a, bias_b, f);
+  const float gg = g[2 * F + f] + gate_bias(bias_a, bias_b, 2 * F + f);
+  const float go = g[3 * F + f] + gate_bias(bias_a, bias_b, 3 * F + f);
+  const float c = sigmoidf(gi) * tanhf(gg);
+  const float out = sigmoidf(go) * tanhf(c);
   h[r * ld_h + f] = (nonempty == nullptr || nonempty[r] != 0.f) ? out : 0.f;
 }
 
 __global__ void lstm_cell0_bwd_kernel(const float* __restrict__ gates, int64_t ld_g,
                                       const float* __restrict__ nonempty,
-                                      const float* __restrict__ dh, int64_t ld_dh, int64_t m, int F,
+                                      const float* __restrict__ dh, int64_t ld_dh, int64_t m,
+                                      const int64_t* __restrict__ m_dev, int F,
+                                      const float* __restrict__ bias_a, const float* __restrict__ bias_b,
                                       float* __restrict__ dgates, int64_t ld_dg) {
   const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= m * F) return;
+  if (i >= dev_count(m_dev, m) * F) return;
   const int64_t r = i / F;
   const int f = static_cast<int>(i - r * F);
   const float* g = gates + r * ld_g;
   float* dg = dgates + r * ld_dg;
   float d = dh[r * ld_dh + f];
   if (nonempty != nullptr && nonempty[r] == 0.f) d = 0.f;
-  const float si = sigmoidf(g[f]), tg = tanhf(g[2 * F + f]), so = sigmoidf(g[3 * F + f]);
+  const float si = sigmoidf(g[f] + gate_bias(bias_a, bias_b, f));
+  const float tg = tanhf(g[2 * F + f] + gate_bias(bias_a, bias_b, 2 * F + f));
+  const float so = sigmoidf(g[3 * F + f] + gate_bias(bias_a, bias_b, 3 * F + f));
   const float c = si * tg;
   const float tc = tanhf(c);
   const float dc = d * so * (1.f - tc * tc);
@@ -77,10 +92,114 @@ __global__ void lstm_cell0_bwd_kernel(const float* __restrict__ gates, int64_t l
   dg[3 * F + f] = d * tc * so * (1.f - so);
 }
 
+// x_flat[t, j F : (j+1) F] = x[row(t, j)]: the flattened input of the cell (reference
+// layers/sage.py:164, :179) for every target of a layer, slot rule as in segment_slots_kernel —
+// the first n_in neighbours in edge order, padded with the first, through node_map if given.
+// One workgroup per target, a wave per slot in turn; VEC floats per lane and access (the slot
+// offsets j F are only as aligned as F is: F = 602 -> 8 bytes).
+template <int VEC>
+__global__ void __launch_bounds__(kBlock)
+lstm_gather_flat_kernel(const float* __restrict__ x, int64_t ld_x, const int64_t* __restrict__ node_map,
+                        const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src,
+                        int64_t num_targets, const int64_t* __restrict__ m_dev, int n_in, int F,
+                        float* __restrict__ xflat, int64_t ld_flat, float* __restrict__ nonempty) {
+  const int64_t t = blockIdx.x;
+  if (t >= dev_count(m_dev, num_targets)) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int64_t s0 = seg_ptr[t];
+  const int64_t len = seg_ptr[t + 1] - s0;
+  if (threadIdx.x == 0) nonempty[t] = len > 0 ? 1.f : 0.f;
+  float* orow = xflat + t * ld_flat;
+  for (int j = wave; j < n_in; j += kBlock / kWave) {
+    int64_t id = 0;
+    if (len > 0) {
+      id = src[s0 + (j < len ? j : 0)];
+      if (node_map != nullptr) id = node_map[id];
+    }
+    const float* irow = x + id * ld_x;
+    float* o = orow + static_cast<int64_t>(j) * F;
+    if (VEC == 4) {
+      for (int c = lane; c < F / 4; c += kWave)
+        reinterpret_cast<float4*>(o)[c] = len > 0 ? reinterpret_cast<const float4*>(irow)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (VEC == 2) {
+      for (int c = lane; c < F / 2; c += kWave)
+        reinterpret_cast<float2*>(o)[c] = len > 0 ? reinterpret_cast<const float2*>(irow)[c] : make_float2(0.f, 0.f);
+    } else {
+      for (int c = lane; c < F; c += kWave) o[c] = len > 0 ? irow[c] : 0.f;
+    }
+  }
+}
+
+// dx[row(t, j)] += d x_flat[t, j F : (j+1) F] — what autograd derives for the index_select that
+// builds x_flat (a padded slot sends its gradient to the first neighbour as well).  fp32 atomics,
+// a lane owns columns lane + 64 k (256 contiguous bytes per wave instruction).
+__global__ void __launch_bounds__(kBlock)
+lstm_scatter_flat_kernel(const float* __restrict__ dflat, int64_t ld_flat, const int64_t* __restrict__ seg_ptr,
+                         const int64_t* __restrict__ src, int64_t num_targets,
+                         const int64_t* __restrict__ m_dev, int n_in, int F, float* __restrict__ dx,
+                         int64_t ld_dx) {
+  const int64_t t = blockIdx.x;
+  if (t >= dev_count(m_dev, num_targets)) return;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const int64_t s0 = seg_ptr[t];
+  const int64_t len = seg_ptr[t + 1] - s0;
+  if (len <= 0) return;                 // (its gates received no gradient)
+  const float* irow = dflat + t * ld_flat;
+  for (int j = wave; j < n_in; j += kBlock / kWave) {
+    const int64_t id = src[s0 + (j < len ? j : 0)];
+    const float* in = irow + static_cast<int64_t>(j) * F;
+    float* o = dx + id * ld_dx;
+    for (int c = lane; c < F; c += kWave) atomicAdd(o + c, in[c]);
+  }
+}
+
 }  // namespace
 }  // namespace sage
 
 using namespace sage;
+
+extern "C" int sage_lstm_gather_flat(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                                     const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                                     const sage_i64* num_targets_dev, int n_in, int num_features,
+                                     float* x_flat, sage_i64 ld_flat, float* nonempty, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(num_targets >= 0 && n_in > 0 && num_features > 0 && ld_x >= num_features &&
+                   ld_flat >= static_cast<int64_t>(n_in) * num_features,
+               SAGE_EINVAL, "sage_lstm_gather_flat: bad sizes");
+  if (num_targets == 0) return SAGE_OK;
+  SAGE_REQUIRE(x && seg_ptr && src && x_flat && nonempty, SAGE_EINVAL, "sage_lstm_gather_flat: NULL pointer argument");
+  auto aligned = [&](int bytes) {
+    return (reinterpret_cast<uintptr_t>(x) % bytes) == 0 && (reinterpret_cast<uintptr_t>(x_flat) % bytes) == 0 &&
+           (ld_x * 4) % bytes == 0 && (ld_flat * 4) % bytes == 0 && (num_features * 4) % bytes == 0;
+  };
+  const unsigned grid = static_cast<unsigned>(num_targets);
+#define SAGE_LSTM_GATHER(V)                                                                                        \
+  lstm_gather_flat_kernel<V><<<grid, kBlock, 0, stream>>>(x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev, \
+                                                         n_in, num_features, x_flat, ld_flat, nonempty)
+  if (aligned(16)) SAGE_LSTM_GATHER(4);
+  else if (aligned(8)) SAGE_LSTM_GATHER(2);
+  else SAGE_LSTM_GATHER(1);
+#undef SAGE_LSTM_GATHER
+  SAGE_CHECK_LAUNCH("lstm_gather_flat_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_lstm_scatter_flat(const float* d_flat, sage_i64 ld_flat, const sage_i64* seg_ptr,
+                                      const sage_i64* src, sage_i64 num_targets, const sage_i64* num_targets_dev,
+                                      int n_in, int num_features, float* dx, sage_i64 ld_dx, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(num_targets >= 0 && n_in > 0 && num_features > 0 && ld_dx >= num_features &&
+                   ld_flat >= static_cast<int64_t>(n_in) * num_features,
+               SAGE_EINVAL, "sage_lstm_scatter_flat: bad sizes");
+  if (num_targets == 0) return SAGE_OK;
+  SAGE_REQUIRE(d_flat && seg_ptr && src && dx, SAGE_EINVAL, "sage_lstm_scatter_flat: NULL pointer argument");
+  lstm_scatter_flat_kernel<<<static_cast<unsigned>(num_targets), kBlock, 0, stream>>>(
+      d_flat, ld_flat, seg_ptr, src, num_targets, num_targets_dev, n_in, num_features, dx, ld_dx);
+  SAGE_CHECK_LAUNCH("lstm_scatter_flat_kernel");
+  return SAGE_OK;
+}
 
 extern "C" int sage_segment_slots(const sage_i64* seg_ptr, const sage_i64* src,
                                   const sage_i64* node_map, sage_i64 num_targets, int n_in,
@@ -97,8 +216,8 @@ extern "C" int sage_segment_slots(const sage_i64* seg_ptr, const sage_i64* src,
 }
 
 extern "C" int sage_lstm_cell0_fwd(const float* gates, sage_i64 ld_gates, const float* nonempty,
-                                   sage_i64 m, int num_features, float* h, sage_i64 ld_h,
-                                   void* stream_) {
+                                   sage_i64 m, const sage_i64* m_dev, int num_features, const float* bias_a,
+                                   const float* bias_b, float* h, sage_i64 ld_h, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(m >= 0 && num_features > 0 && ld_gates >= 4 * static_cast<int64_t>(num_features) &&
                    ld_h >= num_features,
@@ -106,13 +225,14 @@ extern "C" int sage_lstm_cell0_fwd(const float* gates, sage_i64 ld_gates, const 
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(gates && h, SAGE_EINVAL, "sage_lstm_cell0_fwd: NULL pointer argument");
   lstm_cell0_fwd_kernel<<<static_cast<unsigned>(cdiv(m * num_features, kBlock)), kBlock, 0, stream>>>(
-      gates, ld_gates, nonempty, m, num_features, h, ld_h);
+      gates, ld_gates, nonempty, m, m_dev, num_features, bias_a, bias_b, h, ld_h);
   SAGE_CHECK_LAUNCH("lstm_cell0_fwd_kernel");
   return SAGE_OK;
 }
 
 extern "C" int sage_lstm_cell0_bwd(const float* gates, sage_i64 ld_gates, const float* nonempty,
-                                   const float* dh, sage_i64 ld_dh, sage_i64 m, int num_features,
+                                   const float* dh, sage_i64 ld_dh, sage_i64 m, const sage_i64* m_dev,
+                                   int num_features, const float* bias_a, const float* bias_b,
                                    float* dgates, sage_i64 ld_dgates, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(m >= 0 && num_features > 0 && ld_gates >= 4 * static_cast<int64_t>(num_features) &&
@@ -121,7 +241,7 @@ extern "C" int sage_lstm_cell0_bwd(const float* gates, sage_i64 ld_gates, const 
   if (m == 0) return SAGE_OK;
   SAGE_REQUIRE(gates && dh && dgates, SAGE_EINVAL, "sage_lstm_cell0_bwd: NULL pointer argument");
   lstm_cell0_bwd_kernel<<<static_cast<unsigned>(cdiv(m * num_features, kBlock)), kBlock, 0, stream>>>(
-      gates, ld_gates, nonempty, dh, ld_dh, m, num_features, dgates, ld_dgates);
+      gates, ld_gates, nonempty, dh, ld_dh, m, m_dev, num_features, bias_a, bias_b, dgates, ld_dgates);
   SAGE_CHECK_LAUNCH("lstm_cell0_bwd_kernel");
   return SAGE_OK;
 }

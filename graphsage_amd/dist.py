@@ -33,8 +33,11 @@ _staging = {}
 def _all_reduce_staged(flat_grad, group):
     """gloo with a DEVICE tensor (tests and rehearsals with several ranks on one GPU; the
     production backend is nccl): stage through pinned host memory on the caller's stream and
-    run the collective on the host copy.  ProcessGroupGloo's own device path (a pool of 32
-    side streams, one per collective) was seen to hang here with two ranks sharing a GPU."""
+    run the collective on the host copy.  ProcessGroupGloo's own device path hung here with two
+    ranks sharing a GPU (round 1; gpurun_out/dp_sync.log: between steps 30 and 40 one rank sits
+    in torch.cuda.synchronize(), the other in work.wait() on the collective the first has not
+    joined; with GPU_MAX_HW_QUEUES=32, dp_sync_q32.log, every ten steps take twice as long as
+    the ten before and it ends the same way).  Cause undetermined — DESIGN.md section 4."""
     key = (flat_grad.numel(), flat_grad.dtype)
     host = _staging.get(key)
     if host is None:

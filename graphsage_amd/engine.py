@@ -21,7 +21,13 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
   * the pooling aggregators keep P = relu(pool(x)) per SOURCE row of a layer in a static buffer
     and route d agg back through the reduce and the ReLU in one edge pass
     (sage_pool_linear_fwd / sage_pool_max_bwd / sage_pool_mean_bwd); their large weight
-    gradients run on a forked stream beside that pass.
+    gradients run on a forked stream beside that pass;
+  * the lstm aggregator (reference layers/sage.py:67-69, :147-193 as read in layers/lstm.py)
+    materialises the cell's flattened input x_flat [targets, n_in * F] once per layer and step
+    (sage_lstm_gather_flat: 0.8 GB at the Reddit shape, static, in 288 GB of HBM), so that the
+    gates contraction and its weight gradient are ONE launch per gate block over K = n_in * F with
+    both operands contiguous in k — W_ih lives in the flat parameter buffer with padded rows and
+    is never re-laid, its gradient goes straight into the flat gradient, Adam is the fused kernel.
 """
 import contextlib
 import os
@@ -71,7 +77,9 @@ def new_side_stream(dev, beside):
     return st
 
 # gcn: no root weight (lin_r); the pooling aggregators reduce relu(pool(x_j)) instead of x_j
-_REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max', 'gcn': 'gcn', 'max_pool': 'max', 'mean_pool': 'mean'}
+# lstm: no segment reduce at all — the aggregate is one LSTMCell step over the flattened neighbour rows
+_REDUCE = {'mean': 'mean', 'sum': 'sum', 'max': 'max', 'gcn': 'gcn', 'max_pool': 'max', 'mean_pool': 'mean',
+           'lstm': None}
 
 
 def flatten_parameters(model, pad_to=16):
@@ -146,8 +154,11 @@ class SageTrainEngine:
         self.pool = model.aggregator in ('max_pool', 'mean_pool')
         if self.pool and unsup:
             raise NotImplementedError("engine: the pooling aggregators run the supervised (fig2a) step only")
-        if self.pool:
-            overlap_gather = False    # the layer-0 gather reads P, which needs this step's weights
+        self.lstm = model.aggregator == 'lstm'
+        if self.lstm and unsup:
+            raise NotImplementedError("engine: the lstm aggregator runs the supervised (fig2a) step only")
+        if self.pool or self.lstm:
+            overlap_gather = False    # the layer-0 aggregate needs this step's weights (pool Linear / W_ih)
         # Data parallel: the gradient all-reduce of step i is launched behind the backward's last
         # kernel and its Adam step sits in front of the first kernel of step i+1 that reads the
         # weights.  The one piece of weight-free work that can run on the main stream in between
@@ -253,7 +264,16 @@ class SageTrainEngine:
                     a['dh'] = padded(t_cap, fout)
                 else:
                     a['dy'] = padded(t_cap, fout)     # unsup: gradient w.r.t. the normalised logits
-                if i > 0 or self.pool:
+                if self.lstm:
+                    n_in = int(layer.lstm_n_inputs)
+                    a['n_in'] = n_in
+                    a['xflat'] = padded(t_cap, n_in * fin)      # the cell's flattened input, one row per target
+                    a['gates'] = padded(t_cap, 4 * fin)         # x_flat . W_ih^T (biases are added by the cell kernels)
+                    a['dgates'] = padded(t_cap, 4 * fin)
+                    a['nonempty'] = torch.zeros(t_cap, dtype=torch.float32, device=dev)
+                    if i > 0:
+                        a['dxflat'] = padded(t_cap, n_in * fin)
+                if i > 0 or self.pool or self.lstm:
                     a['dagg'] = padded(t_cap, fin)
                     if self.reduce == 'max':   # the backward routes to the edge that attained the max
                         a['argmax'] = torch.zeros((t_cap, fin), dtype=torch.int64, device=dev)
@@ -477,6 +497,11 @@ class SageTrainEngine:
 
     def _gather_layer0(self, slot, events=None):
         a, buf = self.act[0], self.bufs[slot]
+        if self.lstm:
+            if events is not None:
+                raise NotImplementedError("gather_layer0(events=...): the lstm aggregate is a contraction, not a gather")
+            self._lstm_forward(slot, 0, self.features, buf.node, self.agg0[slot])
+            return
         if self.pool:
             self._pool_forward(slot, 0, self.features, buf.node)
             ops.gather_reduce_fwd(a['P'], buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
@@ -494,6 +519,49 @@ class SageTrainEngine:
         ops.pool_linear_fwd(x, layer.pool.weight, layer.pool.bias, m=a['s_cap'],
                             m_dev=self.n_dev[slot][a['src_hop']], rows=node_map, out=a['P'],
                             dpre=a['dpre'])
+
+    @staticmethod
+    def _lstm_blocks(fdim):
+        """Row blocks of W_ih (torch order i, f, g, o) that reach the output from a zero state: the
+        forget gate multiplies c0 = 0 and is neither computed nor given a gradient."""
+        return ((0, fdim), (2 * fdim, 4 * fdim))
+
+    def _lstm_forward(self, slot, i, x, node_map, agg):
+        """agg[t] = LSTMCell(x_flat[t]) from a zero state for the layer's targets."""
+        a, layer, buf = self.act[i], self.model.layers[i], self.bufs[slot]
+        t_cap, t_dev, fdim = a['t_cap'], self.n_dev[slot][a['hop']], a['fin']
+        ops.lstm_gather_flat(x, buf.seg_ptr, buf.src, t_cap, a['n_in'], a['xflat'], a['nonempty'],
+                             node_map=node_map, num_targets_dev=t_dev)
+        w = layer.lstm.weight_ih
+        for r0, r1 in self._lstm_blocks(fdim):
+            ops.linear_concat_fwd(a['xflat'], w[r0:r1], m=t_cap, m_dev=t_dev, out=a['gates'][:, r0:r1])
+        ops.lstm_cell0_fwd(a['gates'], a['nonempty'], fdim, m=t_cap, m_dev=t_dev, bias_a=layer.lstm.bias_ih,
+                           bias_b=layer.lstm.bias_hh, out=agg)
+
+    def _lstm_backward(self, slot, i):
+        """d agg -> (cell) d gates -> W_ih / bias gradients and, above layer 0, the input gradient
+        scattered into the previous layer's dh."""
+        a, layer, buf = self.act[i], self.model.layers[i], self.bufs[slot]
+        t_cap, t_dev, fdim = a['t_cap'], self.n_dev[slot][a['hop']], a['fin']
+        if i > 0:      # root term into the previous layer's dh (overwrites its first t rows), d agg beside it
+            ops.linear_dinput2(a['dz'], layer.lin_r.weight, self.act[i - 1]['dh'], layer.lin_l.weight, a['dagg'],
+                               m=t_cap, m_dev=t_dev)
+        else:
+            ops.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
+        ops.lstm_cell0_bwd(a['gates'], a['nonempty'], a['dagg'], fdim, m=t_cap, m_dev=t_dev,
+                           bias_a=layer.lstm.bias_ih, bias_b=layer.lstm.bias_hh, out=a['dgates'])
+        gw, gb_ih, gb_hh = (self.gviews[p] for p in (layer.lstm.weight_ih, layer.lstm.bias_ih, layer.lstm.bias_hh))
+        for r0, r1 in self._lstm_blocks(fdim):
+            ops.linear_dweight(a['dgates'][:, r0:r1], a['xflat'], m=t_cap, m_dev=t_dev, dw=gw[r0:r1],
+                               dbias=gb_ih[r0:r1])
+        _lib.tape_py(lambda: gb_hh.copy_(gb_ih))       # b_ih and b_hh enter the gates as their sum
+        if i > 0:
+            w = layer.lstm.weight_ih
+            (a0, a1), (b0, b1) = self._lstm_blocks(fdim)
+            ops.linear_dinput(a['dgates'][:, a0:a1], w[a0:a1], m=t_cap, m_dev=t_dev, out=a['dxflat'])
+            ops.linear_dinput(a['dgates'][:, b0:b1], w[b0:b1], m=t_cap, m_dev=t_dev, out=a['dxflat'], accumulate=True)
+            ops.lstm_scatter_flat(a['dxflat'], buf.seg_ptr, buf.src, t_cap, a['n_in'], self.act[i - 1]['dh'],
+                                  num_targets_dev=t_dev)
 
     def forward_backward(self, slot=0, skip_gather0=False):
         self._note('forward_backward')
@@ -543,6 +611,8 @@ class SageTrainEngine:
                                           num_targets_dev=t_dev, out=agg, want_argmax=False)
                 elif not skip_gather0:
                     self._gather_layer0(slot)
+            elif self.lstm:
+                self._lstm_forward(slot, i, x, None, agg)
             else:
                 if self.pool:
                     self._pool_forward(slot, i, x, None)
@@ -637,6 +707,8 @@ class SageTrainEngine:
                     lib.linear_dweight(a['dz'], agg_i, m=t_cap, m_dev=t_dev, dw=self.gviews[layer.lin_l.weight])
             if self.pool:
                 self._pool_backward(slot, i, x_in, rows)
+            elif self.lstm:
+                self._lstm_backward(slot, i)
             elif fused and i == L - 1:
                 lib.logit_layer_bwd(a['dz'], buf.seg_ptr, buf.src, self.B, self.reduce, layer.lin_l.weight,
                                     layer.lin_r.weight, act[i - 1]['dh'], self.row_loss, self.loss)
@@ -849,9 +921,10 @@ class SageTrainEngine:
                 newest = self.n_pref - 1
                 main.wait_event(self.ready[newest % self.nslots])
                 self.main_ready_seq = newest
-            if self.pool:
-                # the pooling aggregators' "gather" starts with the pool Linear: it reads the
-                # weights, so the deferred Adam step of the previous batch goes in front of it
+            if self.pool or self.lstm:
+                # the pooling aggregators' "gather" starts with the pool Linear (lstm: the gates
+                # contraction): it reads the weights, so the deferred Adam step of the previous
+                # batch goes in front of it
                 self.flush()
             if before_gather is not None:
                 before_gather()

@@ -113,7 +113,7 @@ def run(aggregator, dataset=None, num_epochs=None, batch_size=BATCH_SIZE, k1=K1,
     engine = None
     n_train = train_loader._idx_dev.numel()
     if use_engine is None:
-        use_engine = aggregator in ('mean', 'sum', 'max', 'gcn', 'max_pool', 'mean_pool') and n_train >= batch_size
+        use_engine = aggregator in ('mean', 'sum', 'max', 'gcn', 'max_pool', 'mean_pool', 'lstm') and n_train >= batch_size
     if use_engine:
         from ..engine import SageTrainEngine
         graph = train_loader.neighbor_sampler.graph

@@ -922,30 +922,77 @@ def segment_slots(seg_ptr, src, num_targets, n_in, node_map=None):
     return slots, nonempty
 
 
-def lstm_cell0_fwd(gates, nonempty, num_features):
+def lstm_cell0_fwd(gates, nonempty, num_features, m=None, m_dev=None, bias_a=None, bias_b=None, out=None):
+    """h = sigmoid(o) * tanh(sigmoid(i) * tanh(g)) from a zero state, zero rows where nonempty == 0
+    (reference layers/sage.py:187).  bias_a / bias_b ([4F]): added to the gates on the way in."""
     lib = _lib.load()
     gp, ld_g = _mat(gates, "gates")
-    m = gates.size(0)
-    if gates.size(1) != 4 * num_features or nonempty.numel() < m:
+    m = gates.size(0) if m is None else int(m)
+    if gates.size(1) != 4 * num_features or gates.size(0) < m or nonempty.numel() < m:
         raise RuntimeError("lstm_cell0_fwd: shape mismatch")
-    h = torch.empty((m, num_features), dtype=torch.float32, device=gates.device)
+    for b in (bias_a, bias_b):
+        if b is not None and b.numel() != 4 * num_features:
+            raise RuntimeError("lstm_cell0_fwd: bias must have 4F elements")
+    h = torch.empty((m, num_features), dtype=torch.float32, device=gates.device) if out is None else out
+    if h.size(0) < m or h.size(1) != num_features:
+        raise RuntimeError("lstm_cell0_fwd: bad output buffer")
     hp, ld_h = _mat(h, "h")
-    rc = lib.sage_lstm_cell0_fwd(gp, ld_g, _vec(nonempty, torch.float32, "nonempty"), m, int(num_features),
-                                 hp, ld_h, _stream())
+    rc = lib.sage_lstm_cell0_fwd(gp, ld_g, _vec(nonempty, torch.float32, "nonempty"), m, _count(m_dev, "m_dev"),
+                                 int(num_features), _vec(bias_a, torch.float32, "bias_a", allow_none=True),
+                                 _vec(bias_b, torch.float32, "bias_b", allow_none=True), hp, ld_h, _stream())
     _lib.check(rc, "sage_lstm_cell0_fwd")
     return h
 
 
-def lstm_cell0_bwd(gates, nonempty, dh, num_features):
+def lstm_cell0_bwd(gates, nonempty, dh, num_features, m=None, m_dev=None, bias_a=None, bias_b=None, out=None):
     lib = _lib.load()
     gp, ld_g = _mat(gates, "gates")
     dp, ld_dh = _mat(dh, "dh")
-    m = gates.size(0)
-    if gates.size(1) != 4 * num_features or dh.shape != (m, num_features) or nonempty.numel() < m:
+    m = gates.size(0) if m is None else int(m)
+    if gates.size(1) != 4 * num_features or gates.size(0) < m or dh.size(0) < m or dh.size(1) != num_features \
+            or nonempty.numel() < m:
         raise RuntimeError("lstm_cell0_bwd: shape mismatch")
-    dgates = torch.empty_like(gates)
+    for b in (bias_a, bias_b):
+        if b is not None and b.numel() != 4 * num_features:
+            raise RuntimeError("lstm_cell0_bwd: bias must have 4F elements")
+    dgates = torch.empty_like(gates) if out is None else out
+    if dgates.size(0) < m or dgates.size(1) != 4 * num_features:
+        raise RuntimeError("lstm_cell0_bwd: bad output buffer")
     op, ld_dg = _mat(dgates, "dgates")
     rc = lib.sage_lstm_cell0_bwd(gp, ld_g, _vec(nonempty, torch.float32, "nonempty"), dp, ld_dh, m,
-                                 int(num_features), op, ld_dg, _stream())
+                                 _count(m_dev, "m_dev"), int(num_features),
+                                 _vec(bias_a, torch.float32, "bias_a", allow_none=True),
+                                 _vec(bias_b, torch.float32, "bias_b", allow_none=True), op, ld_dg, _stream())
     _lib.check(rc, "sage_lstm_cell0_bwd")
     return dgates
+
+
+def lstm_gather_flat(x, seg_ptr, src, num_targets, n_in, x_flat, nonempty, node_map=None, num_targets_dev=None):
+    """x_flat[t, j*F:(j+1)*F] = x[row(t, j)] (the cell's flattened input, reference
+    layers/sage.py:164,:179) + nonempty[t]; buffers are the caller's."""
+    lib = _lib.load()
+    xp, ld_x = _mat(x, "x")
+    fp, ld_f = _mat(x_flat, "x_flat")
+    T, F = int(num_targets), x.size(1)
+    if seg_ptr.numel() < T + 1 or x_flat.size(0) < T or x_flat.size(1) != n_in * F or nonempty.numel() < T:
+        raise RuntimeError("lstm_gather_flat: shape mismatch")
+    rc = lib.sage_lstm_gather_flat(xp, ld_x, _vec(node_map, torch.int64, "node_map", allow_none=True),
+                                   _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), T,
+                                   _count(num_targets_dev, "num_targets_dev"), int(n_in), F, fp, ld_f,
+                                   _vec(nonempty, torch.float32, "nonempty"), _stream())
+    _lib.check(rc, "sage_lstm_gather_flat")
+    return x_flat
+
+
+def lstm_scatter_flat(d_flat, seg_ptr, src, num_targets, n_in, dx, num_targets_dev=None):
+    """dx[row(t, j)] += d_flat[t, j*F:(j+1)*F] (backward of lstm_gather_flat without a node_map)."""
+    lib = _lib.load()
+    fp, ld_f = _mat(d_flat, "d_flat")
+    xp, ld_dx = _mat(dx, "dx")
+    T, F = int(num_targets), dx.size(1)
+    if seg_ptr.numel() < T + 1 or d_flat.size(0) < T or d_flat.size(1) != n_in * F:
+        raise RuntimeError("lstm_scatter_flat: shape mismatch")
+    rc = lib.sage_lstm_scatter_flat(fp, ld_f, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), T,
+                                    _count(num_targets_dev, "num_targets_dev"), int(n_in), F, xp, ld_dx, _stream())
+    _lib.check(rc, "sage_lstm_scatter_flat")
+    return dx

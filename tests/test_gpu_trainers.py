@@ -168,7 +168,7 @@ def test_fig2a_harness(dev, aggregator):
         settings.LSTM_NUM_INPUTS = 4
     out = fig2a.get(aggregator, dataset=ds, num_epochs=2, batch_size=128, k1=6, k2=4, verbose=False).run()
     assert set(out) >= {'test_time', 'train_time'}
-    assert out['engine'] == (aggregator != "lstm")       # lstm trains through the module path
+    assert out['engine']                                 # every aggregator of the sweep trains on the engine (lstm since round 3)
     assert out['train_time'] > 0 and out['test_time'] > 0 and out['test_acc'] > 0.5
 
 
