@@ -73,11 +73,31 @@ class PendingReduce:
     def __init__(self):
         self.work = None
         self.active = False
+        self._done = None       # device path: event recorded on the collective's stream
 
-    def launch(self, flat_grad, group=None, force=False):
+    def launch(self, flat_grad, group=None, force=False, stream=None):
+        """stream (device tensors): a stream of the CALLER's choosing that carries the collective.
+        The collective is issued there as a synchronous op — which ProcessGroupNCCL enqueues on
+        the current stream, with no stream or event of its own — between a wait for the launching
+        stream and an event that complete() makes its stream wait for.  The caller thereby picks
+        the hardware queue (graphsage_amd/engine.py probes for one that runs beside its compute
+        streams: a stream from the backend's pool can share the main stream's queue, which puts
+        the collective back on the critical path), and the host pays one cheap call instead of an
+        asynchronous work handle (7.6 against 25.6 us on one rank, scratch/nccl_host_cost.py)."""
         if self.active:
             raise RuntimeError("the previous step's all-reduce has not been completed")
-        self.work = all_reduce_flat(flat_grad, group, async_op=True, force=force)
+        if stream is not None and flat_grad.is_cuda:
+            import torch
+            cur = torch.cuda.current_stream(flat_grad.device)
+            stream.wait_stream(cur)
+            with torch.cuda.stream(stream):
+                all_reduce_flat(flat_grad, group, async_op=False, force=force)
+            if self._done is None:
+                self._done = torch.cuda.Event()
+            self._done.record(stream)
+            self.work = self._done
+        else:
+            self.work = all_reduce_flat(flat_grad, group, async_op=True, force=force)
         self.active = True
 
     def complete(self):
@@ -86,7 +106,10 @@ class PendingReduce:
         if not self.active:
             return False
         work, self.work, self.active = self.work, None, False
-        if work is not None:
+        if work is self._done and work is not None:
+            import torch
+            torch.cuda.current_stream().wait_event(work)
+        elif work is not None:
             work.wait()
         return True
 

@@ -329,6 +329,11 @@ class SageTrainEngine:
         # next; the sampler's result is needed two batches later.
         self.samp = new_side_stream(dev, [main, self.side]) if self.overlap_gather else self.side
         self.pool_fork = new_side_stream(dev, [main]) if (self.pool and not os.environ.get('SAGE_NO_POOL_FORK')) else None
+        # data parallel: the gradient all-reduce runs on a stream of the engine's own, on a hardware
+        # queue that is neither the main stream's nor the sampler's (SAGE_DP_BACKEND_STREAM=1: leave
+        # the stream to the backend — the asynchronous work-handle path)
+        self.comm = (new_side_stream(dev, [main, self.side]) if (self.collective and not os.environ.get('SAGE_DP_BACKEND_STREAM'))
+                     else None)
         self._forked = False
         self.sampled = [torch.cuda.Event() for _ in range(self.nslots)]     # slot sampled (sampler stream)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
@@ -946,7 +951,7 @@ class SageTrainEngine:
             pass
         elif self.collective:
             self._note('allreduce_launch')
-            self._pending.launch(self.grad, self.pg, force=True)
+            self._pending.launch(self.grad, self.pg, force=True, stream=self.comm)
             # bound the host's run-ahead: with RCCL neither the launch nor wait() blocks the host.
             # One event per run_ahead/2 steps, two in flight: the host is 4 to 8 steps ahead.
             half = max(1, self.run_ahead // 2)
