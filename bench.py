@@ -30,6 +30,9 @@ SHAPES = {
     "reddit-small": (23296, 4000000, 602, 41, 15343),   # for quick functional runs only
     # BASELINE.json configs[4] (ogbn-products scale; use with --variant unsup): informational
     "products": (2400000, 62000000, 100, 47, 196615),
+    # BASELINE.json configs[1] (PPI's size as ONE graph: 56,944 nodes, 818,716 edges, 50 features, 121
+    # independent sigmoid labels, BCE-with-logits loss; 44,906 training nodes): informational
+    "ppi": (56944, 818716, 50, 121, 44906),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
@@ -387,6 +390,10 @@ def main():
     t_setup = time.perf_counter()
     gemm_mode = "f32" if os.environ.get("SAGE_GEMM_X3", "")[:1] == "0" else "bf16x3"
     data = reddit_like_device(N, E, Fdim, C, seed=0, device=dev)   # identical on every rank
+    multilabel = args.workload == "ppi"
+    if multilabel:
+        gl = torch.Generator(device=dev).manual_seed(1)
+        data.y = (torch.rand((N, C), generator=gl, device=dev) < 0.3).float()
     graph = device_graph(data)
     feats, labels = graph.features(data), graph.labels(data)
     torch.manual_seed(0)
@@ -558,9 +565,10 @@ def main():
                 pe.step(seeds_of(s_), counter_of(s_))
             torch.cuda.synchronize()
             rec["on"] = False
-            roofline_mfma = mfma_roofline(rec, n_probe, gemm_mode)
-            roofline_mfma["schedule"] = (f"separate run of {n_probe} steps on one stream without call tapes "
-                                         "(every contraction alone on the chip)")
+            roofline_mfma = mfma_roofline(rec, n_probe, gemm_mode) if rec["pairs"] else None   # (none above 1 GFLOP: PPI)
+            if roofline_mfma is not None:
+                roofline_mfma["schedule"] = (f"separate run of {n_probe} steps on one stream without call tapes "
+                                             "(every contraction alone on the chip)")
             del pe
             if pooling:      # there the contractions ARE the dominant kernels
                 roofline, roofline_mfma = roofline_mfma, None
@@ -620,7 +628,7 @@ def main():
                            "ms_per_step": round(r2["elapsed"] / nv * 1e3, 4),
                            "value": round(B * nv / r2["elapsed"], 1), "unit": "seed nodes/s"}
         cpu = None
-        if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a" and args.aggregator == "mean":   # the oracle times fig2a's step
+        if world == 1 and args.cpu_steps > 0 and args.variant == "fig2a" and args.aggregator == "mean" and not multilabel:   # the oracle times fig2a's step
             x_cpu, y_cpu = data.x.cpu(), data.y.cpu()
             colptr, row = graph.colptr.cpu().numpy(), graph.row.cpu().numpy()
             seeds_list = [train[i * B:(i + 1) * B].numpy() for i in range(args.cpu_steps + args.cpu_warmup)]
@@ -639,7 +647,8 @@ def main():
             "config": {"workload": f"{args.workload}-shaped synthetic: N={N} E={E} F={Fdim} C={C}, "
                                    f"B={B}/GPU, fan-out {K}, hidden {args.hidden}, aggregator {args.aggregator}"
                                    + (f" (LSTM_NUM_INPUTS {args.lstm_num_inputs})" if args.aggregator == "lstm" else "") + ", "
-                                   f"Adam lr {args.lr}, " + {"fig2a": "fig2a step (supervised term only)",
+                                   f"Adam lr {args.lr}, " + ("multi-label BCE-with-logits, " if multilabel else "")
+                                   + {"fig2a": "fig2a step (supervised term only)",
                                                        "unsup": "UNSUPERVISED trainer step (random-walk loss, 3 forwards)"}.get(
                                        args.variant, "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},

@@ -76,6 +76,8 @@ SIGNATURES = {
     "sage_softmax_xent_rows": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, _P, c_int64, _P]),
     "sage_logits_xent_fused": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, c_int64, _P,
                                        _P, c_int64, _P, _P, c_int, _P]),
+    "sage_logits_bce_fused": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, c_int, c_float, _P, c_int64, _P, _P,
+                                      c_int64, _P, _P, _P, c_int, _P]),
     "sage_logit_layer_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
                                      _P, _P, c_float, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
     "sage_logit_layer_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,

@@ -335,6 +335,74 @@ logits_xent_fused_kernel(float* __restrict__ z, int64_t ld_z,
   }
 }
 
+// The multi-label form of the kernel above (PPI: 121 independent sigmoid outputs per node,
+// reference examples/ppi_graphsage_supervised.py:30 — BCEWithLogitsLoss on the normalised
+// logits): y = normalize(z); loss = mean over the m x n elements of
+// max(y, 0) - y t + log(1 + exp(-|y|)); dz = d loss / d z.  row_loss[r] = the row's sum / n, so
+// that the mean over rows is the loss.  row_stats (optional, int64 [m, 3]): per row the counts
+// (true positive, false positive, false negative) of the prediction y > 0 — what micro-F1 is made
+// of (graph_level_graphsage_trainers.py:57-58: f1_score(y, out > 0, average='micro')).
+// dz == NULL: forward only.
+__global__ void __launch_bounds__(kBlock)
+logits_bce_fused_kernel(float* __restrict__ z, int64_t ld_z, const float* __restrict__ targets, int64_t ld_t,
+                        const int64_t* __restrict__ label_rows, int64_t m, int n, float grad_scale,
+                        float* __restrict__ y, int64_t ld_y, float* __restrict__ inv_norm,
+                        float* __restrict__ dz, int64_t ld_dz, float* __restrict__ row_loss,
+                        int64_t* __restrict__ row_stats, int clear_z) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (r >= m) return;
+  const float* tr = targets + (label_rows != nullptr ? label_rows[r] : r) * ld_t;
+  float* zr = z + r * ld_z;
+  float ss = 0.f;
+  for (int f = lane; f < n; f += kWave) {
+    const float v = zr[f];
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), kNormEps);
+  const float inv = 1.f / denom;
+  const bool clamped = inv >= 1.f / kNormEps;
+  const float scale = grad_scale / (static_cast<float>(m) * static_cast<float>(n));
+  float dot = 0.f, lsum = 0.f;
+  int tp = 0, fp = 0, fn = 0;
+  for (int f = lane; f < n; f += kWave) {
+    const float yv = zr[f] / denom;
+    const float t = tr[f];
+    lsum += fmaxf(yv, 0.f) - yv * t + log1pf(expf(-fabsf(yv)));
+    const float g = (1.f / (1.f + expf(-yv)) - t) * scale;
+    dot += yv * g;
+    const bool p = yv > 0.f, q = t > 0.5f;
+    tp += (p && q) ? 1 : 0;
+    fp += (p && !q) ? 1 : 0;
+    fn += (!p && q) ? 1 : 0;
+  }
+  dot = clamped ? 0.f : wave_sum(dot);
+  lsum = wave_sum(lsum);
+  if (row_stats != nullptr) {
+    const float ftp = wave_sum(static_cast<float>(tp)), ffp = wave_sum(static_cast<float>(fp)),
+                ffn = wave_sum(static_cast<float>(fn));      // (exact: counts <= n < 2^24)
+    if (lane == 0) {
+      row_stats[r * 3 + 0] = static_cast<int64_t>(ftp);
+      row_stats[r * 3 + 1] = static_cast<int64_t>(ffp);
+      row_stats[r * 3 + 2] = static_cast<int64_t>(ffn);
+    }
+  }
+  if (lane == 0) {
+    if (inv_norm != nullptr) inv_norm[r] = inv;
+    if (row_loss != nullptr) row_loss[r] = lsum / static_cast<float>(n);
+  }
+  for (int f = lane; f < n; f += kWave) {
+    const float yv = zr[f] / denom;
+    if (y != nullptr) y[r * ld_y + f] = yv;
+    if (dz != nullptr) {
+      const float g = (1.f / (1.f + expf(-yv)) - tr[f]) * scale;
+      dz[r * ld_dz + f] = (g - yv * dot) * inv;
+    }
+    if (clear_z) zr[f] = 0.f;
+  }
+}
+
 // Cross-entropy of m rows with one WAVE PER ROW over as many workgroups as that takes; the row
 // losses go to a caller buffer and mean_reduce_kernel sums them in a fixed order (the
 // single-workgroup kernel above walks 512 rows in 35 us: 32 dependent reductions per wave).
@@ -640,6 +708,28 @@ extern "C" int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* l
   SAGE_CHECK_LAUNCH("logits_xent_fused_kernel");
   mean_reduce_kernel<<<1, kBlock, 0, stream>>>(row_loss, m, loss);
   SAGE_CHECK_LAUNCH("mean_reduce_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_logits_bce_fused(float* z, sage_i64 ld_z, const float* targets, sage_i64 ld_targets,
+                                     const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
+                                     float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                                     float* row_loss, float* loss, sage_i64* row_stats, int clear_z,
+                                     void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m > 0 && n > 0 && n < (1 << 24) && ld_z >= n && ld_targets >= n && (dz == nullptr || ld_dz >= n) &&
+                   (y == nullptr || ld_y >= n),
+               SAGE_EINVAL, "sage_logits_bce_fused: bad shape");
+  SAGE_REQUIRE(z && targets && (loss == nullptr || row_loss != nullptr), SAGE_EINVAL,
+               "sage_logits_bce_fused: NULL pointer argument (loss needs row_loss)");
+  logits_bce_fused_kernel<<<static_cast<unsigned>(cdiv(m, kWavesPerBlock)), kBlock, 0, stream>>>(
+      z, ld_z, targets, ld_targets, label_rows, m, n, grad_scale, y, ld_y, inv_norm, dz, ld_dz, row_loss, row_stats,
+      clear_z);
+  SAGE_CHECK_LAUNCH("logits_bce_fused_kernel");
+  if (loss != nullptr) {
+    mean_reduce_kernel<<<1, kBlock, 0, stream>>>(row_loss, m, loss);
+    SAGE_CHECK_LAUNCH("mean_reduce_kernel");
+  }
   return SAGE_OK;
 }
 

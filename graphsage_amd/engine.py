@@ -175,8 +175,17 @@ class SageTrainEngine:
         # (sage_logit_layer_fwd / _bwd) instead of gather / split-K contraction / fused loss and
         # d-input pair / scatter-add / loss mean: supervised step, mean or sum, two or more layers
         last_w = model.layers[-1].lin_l.weight
+        # multi-label targets (PPI: fp32 [N, C] of 0 / 1, BCEWithLogitsLoss on the normalised logits —
+        # reference examples/ppi_graphsage_supervised.py:30) instead of int64 class ids + cross entropy
+        self.multilabel = labels is not None and labels.dim() == 2
+        if self.multilabel:
+            if labels.dtype != torch.float32 or labels.size(1) != last_w.size(0):
+                raise RuntimeError("engine: multi-label targets must be fp32 [N, out_channels]")
+            if unsup is True:
+                raise NotImplementedError("engine: the trainers' combined loss is implemented for single-label targets")
         # SAGE_NO_FUSED_LOGIT=1 keeps the separate kernels (the A/B switch of scratch/hb.sh)
         self.fused_logit = (not os.environ.get('SAGE_NO_FUSED_LOGIT') and not unsup and not self.pool
+                            and not self.multilabel
                             and self.root and self.reduce in ('mean', 'sum') and len(model.layers) >= 2
                             and ops.logit_layer_supported(last_w.size(1), last_w.size(0)))
         # ... and reads the hidden layer's PRE-activation rows (SAGE_NO_PRENORM=1: normalise pass kept)
@@ -653,10 +662,8 @@ class SageTrainEngine:
             return
         if not self.unsup:
             self._forward_layers(slot, 0, skip_gather0)
-            # last layer: normalise + cross-entropy on the seed rows + gradient w.r.t. z, one kernel
-            last = self.act[-1]
-            lib.logits_xent_fused(last['z'], self.labels, buf.node, B, last['y'], last['inv'], last['dz'],
-                                  self.row_loss, self.loss, clear_z=True)
+            # last layer: normalise + loss on the seed rows + gradient w.r.t. z, one kernel
+            self._loss_last(slot, B)
             return
         for v in range(3):
             self._forward_layers(slot, v, skip_gather0)
@@ -677,6 +684,17 @@ class SageTrainEngine:
         for v in range(3):
             last = self.acts[v][-1]
             lib.l2norm_relu_bwd(last['dy'], last['y'], last['inv'], False, m=B, dz=last['dz'])
+
+    def _loss_last(self, slot, m):
+        """normalise + loss over the first m seed rows + d loss / d z: cross entropy on class ids
+        (fig2a/runners/graphsage_runners.py:43) or BCE-with-logits on multi-label targets."""
+        buf, last = self.bufs[slot], self.act[-1]
+        if self.multilabel:
+            ops.logits_bce_fused(last['z'], self.labels, buf.node, m, y=last['y'], inv_norm=last['inv'], dz=last['dz'],
+                                 row_loss=self.row_loss, loss=self.loss, clear_z=True)
+        else:
+            ops.logits_xent_fused(last['z'], self.labels, buf.node, m, last['y'], last['inv'], last['dz'],
+                                  self.row_loss, self.loss, clear_z=True)
 
     def _backward(self, slot, fused=False):
         if self.keep_grads:
@@ -838,8 +856,7 @@ class SageTrainEngine:
         self.last_slot = 0
         buf, last = self.bufs[0], self.act[-1]
         self._forward_layers(0, 0, False)
-        ops.logits_xent_fused(last['z'], self.labels, buf.node, valid, last['y'], last['inv'], last['dz'],
-                              self.row_loss, self.loss, clear_z=True)
+        self._loss_last(0, valid)
         last['z'][valid:self.B].zero_()          # the fused kernel consumed (and cleared) `valid` rows only
         last['dz'][valid:self.B].zero_()
         self._backward(0)
@@ -979,9 +996,19 @@ class SageTrainEngine:
         self._note('infer')
         self.last_slot = slot
         B = self.B
-        if not (pred.is_cuda and pred.dtype == torch.int64 and pred.dim() == 1 and pred.is_contiguous()
-                and pred.numel() >= B):
-            raise RuntimeError("infer_pred must be a contiguous CUDA int64 vector of at least B elements")
+        if not (pred.is_cuda and pred.dtype == torch.int64 and pred.is_contiguous()
+                and pred.numel() >= B * (3 if self.multilabel else 1)):
+            raise RuntimeError("infer_pred must be a contiguous CUDA int64 buffer of at least B elements "
+                               "([B, 3] for multi-label targets)")
+        if self.multilabel:
+            # forward of every layer, then normalise + per-row (tp, fp, fn) of the prediction y > 0
+            buf, last = self.bufs[slot], self.act[-1]
+
+            def run_ml():
+                self._forward_layers(slot, 0, True)
+                ops.logits_bce_fused(last['z'], self.labels, buf.node, B, y=last['y'], row_stats=pred, clear_z=True)
+            self._taped_last_ptr('inferml', slot, run_ml, 15, pred)
+            return
         if not self.fused_logit:
             if self.unsup:
                 self.make_pos_neg(slot, self.slot_counter[slot])
@@ -996,10 +1023,15 @@ class SageTrainEngine:
             self._forward_layers(slot, 0, True, upto=self.L - 1)
             ops.logit_layer_infer(prev['h'], buf.seg_ptr, buf.src, B, self.reduce, layer.lin_l.weight,
                                   layer.lin_r.weight, y=last['y'], pred=pred)
+        self._taped_last_ptr('infer', slot, run, 15, pred)       # sage_logit_layer_infer(..., pred, stream)
+
+    def _taped_last_ptr(self, what, slot, run, arg_index, out):
+        """_taped() for a call sequence whose LAST C call writes to a buffer that changes from call
+        to call (the evaluation pass's output slice): replayed with that one pointer patched."""
         if not self.use_tapes:
             run()
             return
-        key = ('infer', slot, torch.cuda.current_stream().cuda_stream)
+        key = (what, slot, torch.cuda.current_stream().cuda_stream)
         entry = self._tapes.get(key)
         if entry is None:
             with _lib.recording() as tape:
@@ -1009,7 +1041,7 @@ class SageTrainEngine:
             return
         head, fn, args, name = entry
         _lib.replay(head)
-        args[15] = pred.data_ptr()           # sage_logit_layer_infer(..., pred, stream)
+        args[arg_index] = out.data_ptr()
         _lib.check(fn(*args), name)
 
     def flush(self):
@@ -1062,6 +1094,8 @@ class SageTrainEngine:
         tensors — accuracy = micro-F1 for single-label classification (what
         f1_score(average='micro') returns in trainers/node_level_graphsage_trainers.py:56-57).
         Sampled fan-out neighbourhoods as in GraphSAGE.inference (models/graphsage.py:51-68).
+        Multi-label targets: returns (tp, fp, fn) of the prediction y > 0 over all seeds and labels
+        (graph_level_graphsage_trainers.py:57-58: f1_score(y, out > 0, average='micro')).
         Runs on the training pipeline (pipelined_step(infer_pred=...)): the sampler `depth`
         batches ahead on its stream, with overlap_gather the layer-0 gather of batch b+1 beside
         the contraction of batch b, call tapes, one launch for the class-logit layer, no torch op
@@ -1074,7 +1108,8 @@ class SageTrainEngine:
         B = self.B
         n = seeds.numel()
         nb = (n + B - 1) // B
-        pred_all = torch.empty(max(nb, 1) * B, dtype=torch.int64, device=self.dev)
+        width = 3 if self.multilabel else 1
+        pred_all = torch.empty(max(nb, 1) * B * width, dtype=torch.int64, device=self.dev)
         if n < nb * B:      # pad the tail with its first seed; the padded rows are not compared
             padded = torch.cat([seeds, seeds[(nb - 1) * B:(nb - 1) * B + 1].expand(nb * B - n)]).contiguous()
         else:
@@ -1086,7 +1121,10 @@ class SageTrainEngine:
         for b in range(nb):
             nxt = padded[(b + d) * B:(b + d + 1) * B] if b + d < nb else None
             self.pipelined_step(nxt, counter0 + b + d if nxt is not None else None,
-                                infer_pred=pred_all[b * B:(b + 1) * B])
+                                infer_pred=pred_all[b * B * width:(b + 1) * B * width])
+        if self.multilabel:      # (tp, fp, fn) over the real seeds: micro-F1 = 2 tp / (2 tp + fp + fn)
+            tp, fp, fn = pred_all.view(-1, 3)[:n].sum(dim=0).view(3, 1).unbind(0)
+            return tp, fp, fn
         correct = (pred_all[:n] == self.labels[seeds]).sum().view(1)
         count = torch.full((1,), n, dtype=torch.int64, device=self.dev)
         if return_pred:
@@ -1104,6 +1142,8 @@ class SageTrainEngine:
         the caller then walks the loader itself."""
         from .dist import batch_counter
         samp = loader.neighbor_sampler
+        if self.multilabel and return_pred:
+            return None
         if (loader.batch_size != self.B or list(samp.num_neighbors) != self.fanout or samp.seed != self.rng_seed
                 or samp.graph is not self.graph or loader.shuffle or loader.world_size != 1 or loader.drop_last
                 or loader.transform is not None or len(loader.dataset) == 0):

@@ -800,6 +800,35 @@ def logits_xent_fused(z, labels, label_rows, m, y, inv_norm, dz, row_loss, loss,
     _lib.check(rc, "sage_logits_xent_fused")
 
 
+def logits_bce_fused(z, targets, label_rows, m, y=None, inv_norm=None, dz=None, row_loss=None, loss=None,
+                     row_stats=None, grad_scale=1.0, clear_z=False):
+    """normalize + BCE-with-logits (mean over m x n elements) + gradient w.r.t. z in one pass —
+    the multi-label last layer (reference examples/ppi_graphsage_supervised.py:30).  targets: fp32
+    [N, n] of 0 / 1, read through label_rows.  dz=None: forward only; row_stats int64 [m, 3]:
+    per-row (tp, fp, fn) of the prediction y > 0."""
+    lib = _lib.load()
+    zp, ld_z = _mat(z, "z")
+    tp_, ld_t = _mat(targets, "targets")
+    n = z.size(1)
+    m = int(m)
+    yp, ld_y = (None, 0) if y is None else _mat(y, "y")
+    dp, ld_dz = (None, 0) if dz is None else _mat(dz, "dz")
+    if z.size(0) < m or m <= 0 or targets.size(1) != n or (dz is not None and (dz.size(0) < m or dz.size(1) != n)) \
+            or (y is not None and (y.size(0) < m or y.size(1) != n)) or (row_loss is not None and row_loss.numel() < m) \
+            or (inv_norm is not None and inv_norm.numel() < m) or (loss is not None and row_loss is None) \
+            or (label_rows is not None and label_rows.numel() < m) or (label_rows is None and targets.size(0) < m) \
+            or (row_stats is not None and (row_stats.numel() < 3 * m or not row_stats.is_contiguous())):
+        raise RuntimeError("logits_bce_fused: bad buffers")
+    rc = lib.sage_logits_bce_fused(zp, ld_z, tp_, ld_t, _vec(label_rows, torch.int64, "label_rows", allow_none=True),
+                                   m, n, float(grad_scale), yp, ld_y,
+                                   _vec(inv_norm, torch.float32, "inv_norm", allow_none=True), dp, ld_dz,
+                                   _vec(row_loss, torch.float32, "row_loss", allow_none=True),
+                                   _p(loss, torch.float32, "loss", allow_none=True),
+                                   _p(row_stats, torch.int64, "row_stats", allow_none=True),
+                                   1 if clear_z else 0, _stream())
+    _lib.check(rc, "sage_logits_bce_fused")
+
+
 def logit_layer_supported(h, n):
     """Whether sage_logit_layer_fwd / _bwd take a [n, h] + [n, h] weight pair (n outputs, width h)."""
     return n <= 64 and h % 4 == 0 and h <= 1024 and n * 2 * h * 4 <= 160 * 1024

@@ -481,6 +481,20 @@ int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* labels,
                            float* row_loss /*[m]*/, float* loss /*[1]*/,
                            int clear_z /* 1: z rows are zeroed after use */, void* stream);
 
+/* The multi-label form (PPI: n independent sigmoid outputs per node, BCEWithLogitsLoss on the
+ * normalised logits — examples/ppi_graphsage_supervised.py:30, trainers/
+ * graph_level_graphsage_trainers.py:36-37): y = normalize(z), loss = mean over the m x n elements
+ * of max(y,0) - y*t + log(1 + exp(-|y|)) with t = targets[label_rows ? label_rows[r] : r, f]
+ * (float 0 / 1), dz = d loss / d z.  row_loss[r] = the row's sum / n.  row_stats (optional,
+ * sage_i64 [m, 3]): per row (true positive, false positive, false negative) counts of the
+ * prediction y > 0 against t > 0.5 — micro-F1's ingredients (graph_level_graphsage_trainers.py:
+ * 57-58).  dz == NULL: forward only (evaluation); loss == NULL: no mean; y / inv_norm optional. */
+int sage_logits_bce_fused(float* z, sage_i64 ld_z, const float* targets, sage_i64 ld_targets,
+                          const sage_i64* label_rows, sage_i64 m, int n, float grad_scale,
+                          float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                          float* row_loss /*[m]*/, float* loss /*[1]*/, sage_i64* row_stats /*[m,3]*/,
+                          int clear_z, void* stream);
+
 /* The class-logit layer of the supervised step — the last SAGE layer on the m seed rows
  * (layers/sage.py:99-134 called from models/graphsage.py:44-49, sliced [:batch_size] at
  * fig2a/runners/graphsage_runners.py:41-43) — in one launch each way, for reduce = mean or sum

@@ -115,6 +115,72 @@ def test_cora_true_shape_training_matches_oracle(dev):
     assert int(count) == 1000 and abs(int(correct) - hit) <= 5      # within 0.5 pt micro-F1
 
 
+# ------------------------------------------------------------------------------------ configs[1]
+def test_ppi_shaped_multilabel_engine_steps_match_oracle(dev):
+    """BASELINE.json configs[1] on the static-shape engine: PPI-shaped graph (F = 50, 121 sigmoid
+    labels), GraphSAGE-mean 50 -> 256 -> 121, fan-out 25/10, B = 512, BCEWithLogitsLoss on the
+    normalised logits of the seed rows (examples/ppi_graphsage_supervised.py:30) — three Adam
+    steps against the oracle (same sampled batches): loss, gradients, parameters; then the
+    evaluation pass's (tp, fp, fn) -> micro-F1 against the oracle's forward on the same
+    sampled neighbourhoods (graph_level_graphsage_trainers.py:57-58)."""
+    from graphsage_amd.datasets import PPI
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = PPI(split='val')[0]
+    n = data.num_nodes
+    layers = make_layers([50, 256, 121], "mean", 6)
+    model = GraphSAGE(50, 256, "mean", 2, 121).to(dev)
+    load_layers(model, layers)
+    graph = device_graph(data)
+    engine = SageTrainEngine(model, NeighborSampler(data, FAN, seed=5), graph.features(data), graph.labels(data), B,
+                             lr=1e-2, keep_grads=True)
+    assert engine.multilabel and not engine.fused_logit
+    c0, r0, _ = csc.to_csc(data.edge_index.numpy(), n)
+    ref = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
+    opt = torch.optim.Adam([v for p in ref for v in p.values()], lr=1e-2)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(4))
+
+    def sampled(seeds, counter):
+        node, src, dst, _, _, _ = sampler.neighbor_sample(c0, r0, seeds.numpy(), FAN, 5, counter)
+        return torch.from_numpy(np.asarray(node)), torch.stack([torch.from_numpy(np.asarray(src)),
+                                                                torch.from_numpy(np.asarray(dst))])
+    for step in range(3):
+        seeds = perm[step * B:(step + 1) * B]
+        loss = engine.step(seeds.to(dev), counter=40 + step)
+        node, ei = sampled(seeds, 40 + step)
+        assert torch.equal(engine.buf.node[:node.numel()].cpu(), node)
+        opt.zero_grad()
+        out_ref = sage_ref.graphsage_forward(data.x[node], ei, ref, "mean")[:B]
+        loss_ref = F.binary_cross_entropy_with_logits(out_ref, data.y[seeds])
+        loss_ref.backward()
+        torch.testing.assert_close(loss.cpu().view(()), loss_ref.detach(), rtol=1e-5, atol=1e-6)
+        for m, p in zip(model.layers, ref):
+            torch.testing.assert_close(engine.gviews[m.lin_l.weight].cpu(), p["lin_l"].grad, rtol=1e-3, atol=1e-6)
+            torch.testing.assert_close(engine.gviews[m.lin_r.weight].cpu(), p["lin_r"].grad, rtol=1e-3, atol=1e-6)
+        opt.step()
+        for m, p in zip(model.layers, ref):
+            torch.testing.assert_close(m.lin_l.weight.data.cpu(), p["lin_l"].detach(), rtol=1e-4, atol=2e-5)
+    # evaluation: 700 nodes = one full batch + a padded tail
+    test_ids = perm[-700:]
+    tp, fp, fn = engine.evaluate(test_ids.to(dev), counter0=900)
+    want = torch.zeros(3, dtype=torch.int64)
+    with torch.no_grad():
+        for b in range(2):
+            chunk = test_ids[b * B:(b + 1) * B]
+            valid = chunk.numel()
+            node, ei = sampled(torch.cat([chunk, chunk[:1].expand(B - valid)]), 900 + b)
+            out = sage_ref.graphsage_forward(data.x[node], ei, ref, "mean")[:valid]
+            p, t = out > 0, data.y[chunk] > 0.5
+            want += torch.tensor([int((p & t).sum()), int((p & ~t).sum()), int((~p & t).sum())])
+    got = torch.tensor([int(tp), int(fp), int(fn)])
+    assert int((got - want).abs().max()) <= 6, (got, want)      # logits within 1e-5 of zero may fall either way
+    f1 = 2 * int(tp) / (2 * int(tp) + int(fp) + int(fn))
+    f1_ref = 2 * int(want[0]) / (2 * int(want[0]) + int(want[1]) + int(want[2]))
+    assert abs(f1 - f1_ref) < 1e-3
+
+
 # ------------------------------------------------------------------------------------ configs[3]
 def _reddit_batch(graph, dev, counter=5):
     from graphsage_amd import ops
