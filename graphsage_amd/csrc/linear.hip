@@ -1259,6 +1259,29 @@ bool xcd_mode() {
   return v == nullptr || v[0] != '0';
 }
 
+// Split-K factor of a weight-gradient launch with `tiles` output tiles on `slots` resident
+// workgroups.  Few tiles: as many slices as fill one round.  MORE tiles than slots (the lstm
+// cell's W_ih gradient: 590 and 1,180 tiles of 128 x 128 on 512 slots — 2 and 3 rounds of which
+// the last is 15 / 30 % full, SQ_BUSY_CU_CYCLES 70 % of the launch): the factor in 1..8 whose
+// slices x tiles fill whole rounds best (590 x 6 = 3,540 on 7 x 512 = 3,584), if that wins at
+// least 5 % over no split — the partial sums are fp32 atomics into dw either way.
+int64_t balanced_splits(int64_t tiles, int64_t slots, int64_t max_splits) {
+  int64_t sp = slots / tiles;
+  if (tiles > slots) {
+    auto fill = [&](int64_t f) { return static_cast<double>(tiles * f) / static_cast<double>(cdiv(tiles * f, slots) * slots); };
+    sp = 1;
+    double best = fill(1) * 1.05;
+    for (int64_t f = 2; f <= 8; ++f) {
+      if (fill(f) > best) {
+        best = fill(f);
+        sp = f;
+      }
+    }
+  }
+  if (sp > max_splits) sp = max_splits;
+  return sp < 1 ? 1 : sp;
+}
+
 bool x3_mode() {
   const char* v = getenv("SAGE_GEMM_X3");
   return v == nullptr || v[0] != '0';
@@ -1567,8 +1590,13 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
     // 970 tiles on 512 slots; the headline's 208 are not, they stay stream-K pieces of 64 x 128)
     const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
     const int64_t t128 = cdiv(m, 128) * cdiv(n, 128);
+    // (a capacity that overshoots a whole number of rounds by at most 3 % counts as filling it:
+    // the row count of a sampled batch is below its capacity whenever two seeds share a
+    // neighbour — the lstm cell's i-gate block, 520 tiles for the capacity of 13,312 rows, has
+    // 485-495 for the 12.4-12.6 k rows a Reddit-shaped batch really holds)
     const bool fill128 = slots > 0 && !(bm_env && bm_env[0] == '6') &&
-                         (t128 >= 2ll * slots || t128 * 10 >= cdiv(t128, slots) * slots * 9);
+                         (t128 >= 2ll * slots || t128 * 10 >= cdiv(t128, slots) * slots * 9 ||
+                          (t128 > slots && t128 % slots * 100 <= 3 * slots && m_dev != nullptr));
     const bool whole = tiles >= 8 * grid_x3 || !plain || cdiv(k1, BK) + cdiv(k2, BK) <= 12 || fill128;
     if (x3_mode() && (plain || whole) && n > 64 && slots > 0 && vec4 && steps >= 6ll * slots) {
       if (whole) {
@@ -1742,9 +1770,7 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
     if (n >= 256 && !(bm_env && bm_env[0] == '6')) {
       // 128 x 128 tiles, two workgroups per CU: one full round of 512
       const int64_t tiles2 = cdiv(n, 128) * cdiv(k, 128);
-      int64_t sp = 512 / tiles2;
-      if (sp > max_splits) sp = max_splits;
-      if (sp < 1) sp = 1;
+      int64_t sp = balanced_splits(tiles2, 512, max_splits);
       g.k_chunk = static_cast<int>(cdiv(cdiv(m, sp), BK) * BK);
       sp = cdiv(m, g.k_chunk);
       const dim3 grid(static_cast<unsigned>(cdiv(n, 128)), static_cast<unsigned>(cdiv(k, 128)),
@@ -1828,9 +1854,7 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
     const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
     if (n >= 256 && !(bm_env && bm_env[0] == '6')) {
       const int64_t tiles2 = cdiv(n, 128) * (cdiv(k1, 128) + cdiv(k2, 128));
-      int64_t sp = 512 / tiles2;
-      if (sp > max_splits) sp = max_splits;
-      if (sp < 1) sp = 1;
+      int64_t sp = balanced_splits(tiles2, 512, max_splits);
       g.k_chunk = static_cast<int>(cdiv(cdiv(m, sp), BK) * BK);
       sp = cdiv(m, g.k_chunk);
       const dim3 grid(static_cast<unsigned>(cdiv(n, 128)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),

@@ -510,6 +510,43 @@ __global__ void adam_kernel(float* __restrict__ param, const float* grad,
   if (zero_grad) const_cast<float*>(grad)[i] = 0.f;
 }
 
+// The same update, four elements per thread with 16-byte accesses (numel a multiple of 4, all
+// four buffers 16-byte aligned: the engine's flat buffers are): the lstm model's 45 M parameters
+// are eight streams of 180 MB per step — 479 us one float at a time.  Per element the arithmetic
+// is adam_kernel's, operation for operation.
+__global__ void __launch_bounds__(kBlock)
+adam4_kernel(float4* __restrict__ param, float4* grad, float4* __restrict__ exp_avg,
+             float4* __restrict__ exp_avg_sq, int64_t numel4, float lr, float beta1, float beta2, float eps,
+             float weight_decay, float grad_scale, const int64_t* __restrict__ step_in,
+             int64_t* __restrict__ step_out, int zero_grad) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t step = *step_in;
+  if (i == 0 && step_out != nullptr) *step_out = step + 1;
+  if (i >= numel4) return;
+  const float t = static_cast<float>(step + 1);
+  const float bc1 = 1.f - powf(beta1, t);
+  const float bc2 = 1.f - powf(beta2, t);
+  const float sq_bc2 = sqrtf(bc2), step_size = lr / bc1;
+  const float4 g4 = grad[i], p4 = param[i], m4 = exp_avg[i], v4 = exp_avg_sq[i];
+  auto one = [&](float gi, float p, float m0, float v0, float& po, float& mo, float& vo) {
+    float g = gi * grad_scale;
+    if (weight_decay != 0.f) g += weight_decay * p;
+    mo = beta1 * m0 + (1.f - beta1) * g;
+    vo = beta2 * v0 + (1.f - beta2) * g * g;
+    const float denom = sqrtf(vo) / sq_bc2 + eps;
+    po = p - step_size * (mo / denom);
+  };
+  float4 po, mo, vo;
+  one(g4.x, p4.x, m4.x, v4.x, po.x, mo.x, vo.x);
+  one(g4.y, p4.y, m4.y, v4.y, po.y, mo.y, vo.y);
+  one(g4.z, p4.z, m4.z, v4.z, po.z, mo.z, vo.z);
+  one(g4.w, p4.w, m4.w, v4.w, po.w, mo.w, vo.w);
+  exp_avg[i] = mo;
+  exp_avg_sq[i] = vo;
+  param[i] = po;
+  if (zero_grad) grad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ void bump_step2_kernel(const int64_t* step_in, int64_t* step_out) { *step_out = *step_in + 1; }
 
 
@@ -681,9 +718,17 @@ extern "C" int sage_adam_step(float* param, float* grad, float* exp_avg, float* 
   if (numel > 0) {
     SAGE_REQUIRE(param && grad && exp_avg && exp_avg_sq, SAGE_EINVAL,
                  "sage_adam_step: NULL pointer argument");
-    adam_kernel<<<static_cast<unsigned>(cdiv(numel, kBlock)), kBlock, 0, stream>>>(
-        param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale,
-        step_in, in_place ? nullptr : step_out, zero_grad);
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (numel % 4 == 0 && numel >= (1 << 20) && a16(param) && a16(grad) && a16(exp_avg) && a16(exp_avg_sq)) {
+      adam4_kernel<<<static_cast<unsigned>(cdiv(numel / 4, kBlock)), kBlock, 0, stream>>>(
+          reinterpret_cast<float4*>(param), reinterpret_cast<float4*>(const_cast<float*>(grad)),
+          reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), numel / 4, lr, beta1, beta2, eps,
+          weight_decay, grad_scale, step_in, in_place ? nullptr : step_out, zero_grad);
+    } else {
+      adam_kernel<<<static_cast<unsigned>(cdiv(numel, kBlock)), kBlock, 0, stream>>>(
+          param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale,
+          step_in, in_place ? nullptr : step_out, zero_grad);
+    }
     SAGE_CHECK_LAUNCH("adam_kernel");
   }
   if (in_place || numel == 0) {
