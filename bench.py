@@ -525,7 +525,10 @@ def main():
     # One GPU: the overlapped schedule.  Data parallel: the serial one — the layer-0 gather of
     # batch s+1 then sits on the main stream between the all-reduce launch of step s and its
     # Adam step and covers the collective (graphsage_amd/engine.py).
-    overlapped = not args.serial and not use_graph and not pooling and world == 1 and not force_coll
+    # (PPI-sized rows — 50 floats — make every kernel latency-bound: the overlapped schedule's cross-stream
+    # hand-shake then costs more than the 9 us gather it hides, 0.187 against 0.158 ms/step)
+    overlapped = (not args.serial and not use_graph and not pooling and world == 1 and not force_coll
+                  and args.workload != "ppi")
     import copy
     # 1. the roofline probe: serial schedule (every kernel of a step on ONE stream), where the
     #    HBM-bound layer-0 gather has the chip to itself and its event-timed duration is its own
