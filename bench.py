@@ -189,9 +189,14 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense
 
 
 def bracket_contractions(ops):
-    """Wrap the contraction entry points of graphsage_amd.ops: while rec["on"], every call above
-    1 GFLOP is bracketed by a HIP event pair on its stream.  Returns rec (flops, event pairs)."""
-    rec = {"on": False, "flops": 0.0, "pairs": []}
+    """Wrap the contraction entry points of graphsage_amd.ops: while rec["on"], the MFMA kernel of
+    every call above 1 GFLOP carries a HIP event pair (sage_probe_next_contraction: start / stop
+    events attached to the launch — the dispatch's own duration; rec["bracket"] = True records the
+    pair around the call instead, which adds the markers' own cost).  Returns rec (flops, pairs)."""
+    import ctypes
+
+    from graphsage_amd import _lib
+    rec = {"on": False, "flops": 0.0, "pairs": [], "bracket": False}
 
     def bracket(name, flops_of):
         inner = getattr(ops, name)
@@ -204,8 +209,18 @@ def bracket_contractions(ops):
                 return inner(*a, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            out = inner(*a, **kw)
-            e1.record()
+            if rec["bracket"]:
+                out = inner(*a, **kw)
+                e1.record()
+            else:
+                e1.record()          # (torch creates the hipEvent_t on the first record)
+                lib = _lib.load()
+                _lib.check(lib.sage_probe_next_contraction(ctypes.c_void_p(e0.cuda_event), ctypes.c_void_p(e1.cuda_event), 0),
+                           "sage_probe_next_contraction")
+                try:
+                    out = inner(*a, **kw)
+                finally:
+                    lib.sage_probe_next_contraction(None, None, 0)   # (a pair no launch took is dropped)
             rec["flops"] += fl
             rec["pairs"].append((e0, e1))
             return out
@@ -252,8 +267,9 @@ def mfma_roofline(rec, steps, gemm_mode):
             "gemm_ms_per_step": round(t_ms / steps, 4), "launches_per_step": len(rec["pairs"]) / steps,
             "avg_launch_us": round(t_ms / max(len(rec["pairs"]), 1) * 1e3, 2),
             "empty_event_pair_us": round(empty_ms * 1e3, 2),
-            "timing": "HIP events recorded around each call on its stream (fp32-equivalent flops; "
-                      "peak = bf16 dense peak / 6 products in bf16x3 mode)"}
+            "timing": ("HIP events recorded around each call on its stream" if rec.get("bracket") else
+                       "HIP start/stop events attached to each contraction's launch (hipExtLaunchKernelGGL)")
+                      + " (fp32-equivalent flops; peak = bf16 dense peak / 6 products in bf16x3 mode)"}
 
 
 def module_variant(args, data, graph, model, N, E, Fdim, C, n_train, B, K, gemm_mode):
@@ -458,6 +474,22 @@ def main():
                 a0.record()
                 b0.record()
             handles = [(a0.cuda_event, b0.cuda_event) for a0, b0 in ev]
+        # the two large contractions of the fused mean / sum step carry event pairs of their own in
+        # the same run (sage_probe_next_contraction: per step the forward is the first MFMA
+        # contraction this thread launches, the weight-gradient pair the second)
+        probe_mfma = (probe_gather and attached and not graph_replay and not engine.overlap_gather
+                      and engine.fused_logit and engine.L == 2)
+        ev_mm, h_mm = [], []
+        if probe_mfma:
+            import ctypes
+
+            from graphsage_amd import _lib
+            plib = _lib.load()
+            ev_mm = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(steps)]
+            for quad in ev_mm:
+                for e in quad:
+                    e.record()
+            h_mm = [tuple(ctypes.c_void_p(e.cuda_event) for e in quad) for quad in ev_mm]
         cur = {"i": 0}
         if graph_replay:
             engine.capture(mine, counter0=rank, counter_stride=world, split_gather=probe_gather)
@@ -478,6 +510,10 @@ def main():
                 pg_ = probe_gather and timed
                 b = (lambda: ev[cur["i"]][0].record()) if (pg_ and not attached) else None
                 a = (lambda: ev[cur["i"]][1].record()) if (pg_ and not attached) else None
+                if probe_mfma and pg_:
+                    f0, f1, d0, d1 = h_mm[cur["i"]]
+                    plib.sage_probe_next_contraction(f0, f1, 0)
+                    plib.sage_probe_next_contraction(d0, d1, 1)
                 engine.pipelined_step(seeds_of(s + depth), counter_of(s + depth), b, a,
                                       handles[cur["i"]] if (attached and pg_) else None)
         for s in range(settle):
@@ -514,7 +550,12 @@ def main():
         if int(engine.state_sum[ops.ST_ERROR]) != 0:
             raise SystemExit("sampler reported an error during the run")
         ms = torch.tensor([a.elapsed_time(b) for a, b in ev], dtype=torch.float64) if probe_gather else None
-        return {"elapsed": elapsed, "issued": t_issued, "st": st, "gather_ms": ms, "loss": float(engine.loss)}
+        mm = None
+        if probe_mfma:
+            plib.sage_probe_next_contraction(None, None, 0)
+            mm = (sum(q[0].elapsed_time(q[1]) for q in ev_mm), sum(q[2].elapsed_time(q[3]) for q in ev_mm))
+        return {"elapsed": elapsed, "issued": t_issued, "st": st, "gather_ms": ms, "loss": float(engine.loss),
+                "mfma_ms": mm}
 
     def gather_bytes(st, launches):
         e_b = float(st[ops.ST_EDGES])                    # summed over the timed launches
@@ -550,7 +591,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
-        roofline = roofline_mfma = None
+        roofline = roofline_mfma = roofline_mfma_serial = None
         if world == 1 and not args.no_probe and not force_coll and args.variant == "fig2a":
             # MFMA roofline of the contractions: a short run of the same steps with every call
             # going through the wrappers of ops.py (no call tapes), each contraction above
@@ -610,6 +651,26 @@ def main():
                                    else "HIP events recorded around each launch"),
                         "empty_event_pair_us": round(bracket_us, 2),
                         "algorithmic_bytes_per_launch": int(bytes_sum / n_launch), "row_stride_floats": int(feats.stride(0))}
+            if src.get("mfma_ms") is not None:
+                # MFMA roofline of the step's two large contractions from the SAME serial run (taped,
+                # steady clocks): flops from the device-side row counts summed over those launches
+                t1_sum = float(src["st"][ops.ST_HOP_NODES + 1]) * (n_launch / max(float(src["st"][ops.ST_HOP_NODES]) / B, 1.0))
+                fl_each = 2.0 * t1_sum * args.hidden * 2 * Fdim
+                f_ms, d_ms = src["mfma_ms"]
+                peak = MFMA_PEAK_TFLOPS["bf16"] / 6.0 if gemm_mode == "bf16x3" else MFMA_PEAK_TFLOPS["f32"]
+                tf = 2.0 * fl_each / ((f_ms + d_ms) * 1e-3) / 1e12
+                roofline_mfma_serial = {
+                    "bound": "mfma", "kernel": "layer-0 forward contraction + layer-0 weight-gradient pair "
+                                               "(gemm_x3_kernel<64> / gemm_x3_dw_kernel<128>; gemm_kernel with SAGE_GEMM_X3=0)",
+                    "achieved": round(tf, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
+                    "traffic": None, "flops_per_step": 2.0 * fl_each / n_launch,
+                    "forward_avg_launch_us": round(f_ms / n_launch * 1e3, 2),
+                    "dweight_avg_launch_us": round(d_ms / n_launch * 1e3, 2),
+                    "forward_tflops": round(fl_each / (f_ms * 1e-3) / 1e12, 1),
+                    "dweight_tflops": round(fl_each / (d_ms * 1e-3) / 1e12, 1),
+                    "schedule": roofline["schedule"],
+                    "timing": "HIP start/stop events attached to each contraction's launch (hipExtLaunchKernelGGL); "
+                              "fp32-equivalent flops; peak = bf16 dense peak / 6 products in bf16x3 mode"}
             if probe_res is not None:
                 # the same kernel in the headline (overlapped) schedule, where it shares the chip with
                 # the MFMA-bound forward GEMM of the previous batch: longer by contention, not by itself
@@ -655,7 +716,12 @@ def main():
                                                        "unsup": "UNSUPERVISED trainer step (random-walk loss, 3 forwards)"}.get(
                                        args.variant, "TRAINER step (supervised + unsupervised term, 3 forwards)"),
                        "parallelism": f"dp{world}", "global_batch": world * B},
-            "roofline": roofline, "roofline_mfma": roofline_mfma, "cpu_baseline": cpu,
+            "roofline": roofline,
+            # the contractions: from the serial probe run's attached events where that run has them
+            # (the fused mean / sum step), else from the separate untaped run
+            "roofline_mfma": roofline_mfma_serial if roofline_mfma_serial is not None else roofline_mfma,
+            "roofline_mfma_untaped": roofline_mfma if roofline_mfma_serial is not None else None,
+            "cpu_baseline": cpu,
             "schedule": ("HIP-graph replay" if use_graph else
                          "overlapped: layer-0 gather of batch s+1 on the side stream beside batch s" if overlapped
                          else "serial: every kernel of a step on one stream" if (world == 1 and not force_coll)

@@ -1,6 +1,7 @@
 // Shared host/device helpers of libsage_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -10,6 +11,22 @@
 namespace sage {
 
 void set_error(const char* fmt, ...);
+
+// Measurement hook (sage_probe_next_contraction): HIP event pairs that coming contraction launches
+// of this thread carry (hipExtLaunchKernelGGL start / stop events: the dispatch's own duration,
+// not the time between two markers).  take_probe() is called once per contraction launch.
+bool take_probe(hipEvent_t* start, hipEvent_t* stop);
+
+// kernel<<<grid, block, 0, stream>>>(args...) — or the same launch carrying the pending probe events
+#define SAGE_LAUNCH_PROBED(kernel, grid, block, stream, ...)                                        \
+  do {                                                                                              \
+    hipEvent_t pe0_ = nullptr, pe1_ = nullptr;                                                      \
+    if (sage::take_probe(&pe0_, &pe1_)) {                                                           \
+      hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, pe0_, pe1_, 0, __VA_ARGS__); \
+    } else {                                                                                        \
+      hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__);                  \
+    }                                                                                               \
+  } while (0)
 
 #define SAGE_REQUIRE(cond, code, ...) \
   do {                                \

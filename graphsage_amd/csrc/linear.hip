@@ -1315,18 +1315,18 @@ int launch_gemm_vec(const GemmArgs& g, int splits, hipStream_t stream, const cha
   if (g.batched) {  // 64x128 tiles; y covers problem 0 then problem 1
     dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)),
               static_cast<unsigned>(g.ny0 + cdiv(g.n2, 128)), static_cast<unsigned>(splits));
-    gemm_kernel<A_KC, B_KC, 64, 128, VEC><<<grid, kThreads, 0, stream>>>(g);
+    SAGE_LAUNCH_PROBED((gemm_kernel<A_KC, B_KC, 64, 128, VEC>), grid, kThreads, stream, g);
     SAGE_CHECK_LAUNCH(what);
     return SAGE_OK;
   }
   if (g.n > 64) {
     dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)), static_cast<unsigned>(cdiv(g.n, 128)),
               static_cast<unsigned>(splits));
-    gemm_kernel<A_KC, B_KC, 64, 128, VEC><<<grid, kThreads, 0, stream>>>(g);
+    SAGE_LAUNCH_PROBED((gemm_kernel<A_KC, B_KC, 64, 128, VEC>), grid, kThreads, stream, g);
   } else {
     dim3 grid(static_cast<unsigned>(cdiv(g.m, 64)), static_cast<unsigned>(cdiv(g.n, 64)),
               static_cast<unsigned>(splits));
-    gemm_kernel<A_KC, B_KC, 64, 64, VEC><<<grid, kThreads, 0, stream>>>(g);
+    SAGE_LAUNCH_PROBED((gemm_kernel<A_KC, B_KC, 64, 64, VEC>), grid, kThreads, stream, g);
   }
   SAGE_CHECK_LAUNCH(what);
   return SAGE_OK;
@@ -1608,9 +1608,9 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
       }
       g.xcd_map = xcd_mode() ? 1 : 0;
       if (whole && fill128) {
-        gemm_x3_kernel<128><<<dim3(static_cast<unsigned>(slots)), kThreads, 0, stream>>>(g);
+        SAGE_LAUNCH_PROBED((gemm_x3_kernel<128>), static_cast<unsigned>(slots), kThreads, stream, g);
       } else {
-        gemm_x3_kernel<64><<<dim3(static_cast<unsigned>(grid_x3)), kThreads, 0, stream>>>(g);
+        SAGE_LAUNCH_PROBED((gemm_x3_kernel<64>), static_cast<unsigned>(grid_x3), kThreads, stream, g);
       }
       SAGE_CHECK_LAUNCH("gemm_x3_kernel");
       return SAGE_OK;
@@ -1628,9 +1628,9 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
       if (g.seg[sgi].b.vec < vec) vec = g.seg[sgi].b.vec;
     }
     const dim3 grid(static_cast<unsigned>(slots));
-    if (vec == 4) gemm_kernel<true, true, 64, 128, 4><<<grid, kThreads, 0, stream>>>(g);
-    else if (vec == 2) gemm_kernel<true, true, 64, 128, 2><<<grid, kThreads, 0, stream>>>(g);
-    else gemm_kernel<true, true, 64, 128, 1><<<grid, kThreads, 0, stream>>>(g);
+    if (vec == 4) SAGE_LAUNCH_PROBED((gemm_kernel<true, true, 64, 128, 4>), grid, kThreads, stream, g);
+    else if (vec == 2) SAGE_LAUNCH_PROBED((gemm_kernel<true, true, 64, 128, 2>), grid, kThreads, stream, g);
+    else SAGE_LAUNCH_PROBED((gemm_kernel<true, true, 64, 128, 1>), grid, kThreads, stream, g);
     SAGE_CHECK_LAUNCH("gemm_kernel(fwd, stream-K)");
     return SAGE_OK;
   }
@@ -1775,11 +1775,11 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
       sp = cdiv(m, g.k_chunk);
       const dim3 grid(static_cast<unsigned>(cdiv(n, 128)), static_cast<unsigned>(cdiv(k, 128)),
                       static_cast<unsigned>(sp));
-      gemm_x3_dw_kernel<128><<<grid, kThreads, 0, stream>>>(g);
+      SAGE_LAUNCH_PROBED((gemm_x3_dw_kernel<128>), grid, kThreads, stream, g);
     } else {
       const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(cdiv(k, 128)),
                       static_cast<unsigned>(splits));
-      gemm_x3_dw_kernel<64><<<grid, kThreads, 0, stream>>>(g);
+      SAGE_LAUNCH_PROBED((gemm_x3_dw_kernel<64>), grid, kThreads, stream, g);
     }
     SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel");
     return SAGE_OK;
@@ -1859,11 +1859,11 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
       sp = cdiv(m, g.k_chunk);
       const dim3 grid(static_cast<unsigned>(cdiv(n, 128)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
                       static_cast<unsigned>(sp));
-      gemm_x3_dw_kernel<128><<<grid, kThreads, 0, stream>>>(g);
+      SAGE_LAUNCH_PROBED((gemm_x3_dw_kernel<128>), grid, kThreads, stream, g);
     } else {
       const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
                       static_cast<unsigned>(splits));
-      gemm_x3_dw_kernel<64><<<grid, kThreads, 0, stream>>>(g);
+      SAGE_LAUNCH_PROBED((gemm_x3_dw_kernel<64>), grid, kThreads, stream, g);
     }
     SAGE_CHECK_LAUNCH("gemm_x3_dw_kernel(pair)");
     return SAGE_OK;

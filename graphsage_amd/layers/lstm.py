@@ -16,14 +16,18 @@ node ids (:164) and returns rows in set-iteration order (:193) — so there is n
 to match; tests compare against oracle/sage_ref.lstm_aggregate_ref, which restates the list
 above with torch.nn.functional on the CPU, and at the Reddit shape against torch.nn.LSTMCell.
 
-Kernels: slot indices (HIP) -> gates = x_flat @ W_ih^T + b_ih + b_hh on the MFMA GEMM -> zero-state
-cell non-linearity (HIP).  x_flat [T, n_in*F] (0.8 GB at the Reddit shape) is never materialised:
-the contraction runs as n_in K-segments of width F, segment j reading the feature rows through
-its own row map slots[j] (two segments per launch, `out +=`); small target sets (the layers above
-layer 0: T = batch size) materialise x_flat and contract over all slots at once.  The forget gate multiplies the
-zero initial cell state, so its quarter of W_ih is neither multiplied nor given a gradient
-(3/4 of the flops); W_hh multiplies the zero hidden state and receives a zero gradient, exactly
-as in the reference's single-step use.
+Kernels: x_flat [T, n_in*F] materialised once per call (sage_lstm_gather_flat: slot rule and, for
+layer 0, the batch's node vector applied inside the kernel; 0.8 GB at the Reddit shape — nothing
+in 288 GB of HBM) -> gates = x_flat @ W_ih^T on the MFMA GEMM, ONE launch per gate block over
+K = n_in*F with both operands contiguous in k -> zero-state cell non-linearity (HIP, biases added
+on the way in).  Round 2 ran the contraction as n_in K-segments through per-slot row maps (13
+two-segment launches that each read-modify-write the gates) and re-laid W_ih into a padded copy
+on every call; the static-shape engine's route (graphsage_amd/engine.py) replaced
+both, and this module path now calls the same pieces.  W_ih is read in place when its rows are
+16-byte aligned (a model whose parameters the engine flattened), else through ONE padded copy
+(`ops.aligned_rows`).  The forget gate multiplies the zero initial cell state, so its quarter of
+W_ih is neither multiplied nor given a gradient (3/4 of the flops); W_hh multiplies the zero hidden
+state and receives no gradient, exactly as in the reference's single-step use.
 """
 import torch
 from torch.autograd import Function
@@ -36,130 +40,65 @@ def _blocks(fdim):
     return ((0, fdim), (2 * fdim, 4 * fdim))
 
 
-_FLAT_BYTES = 256 << 20      # x_flat is materialised up to this size (the layers above layer 0: T = batch size)
-
-
-class _LstmGatesFlatFn(Function):
-    """The same gates for a SMALL target set (T x n_in x F floats within _FLAT_BYTES, F a multiple
-    of 16 so that every slot's columns are 64-byte aligned): x_flat [T, n_in*F] is gathered once and
-    the contraction over all slots is one launch per row block of W_ih — at T = 512 the per-slot
-    K-segment launches are 16-workgroup grids of 11-13 us each, 2 x 26 of them per step."""
-
-    @staticmethod
-    def forward(ctx, x, slots, w_ih, bias):
-        n_in, T = slots.shape
-        fdim = x.size(1)
-        idx = slots.t().reshape(-1)                      # row t*n_in + j = slot j of target t
-        x_flat = x.index_select(0, idx).view(T, n_in * fdim)
-        w = w_ih.detach()
-        gates = bias.unsqueeze(0).expand(T, 4 * fdim).contiguous()
-        for r0, r1 in _blocks(fdim):
-            ops.linear_concat_fwd(x_flat, w[r0:r1], m=T, out=gates[:, r0:r1], accumulate=True)
-        ctx.save_for_backward(x_flat, idx, w)
-        ctx.fdim, ctx.n_rows = fdim, x.size(0)
-        return gates
-
-    @staticmethod
-    def backward(ctx, dgates):
-        x_flat, idx, w = ctx.saved_tensors
-        fdim = ctx.fdim
-        T = x_flat.size(0)
-        dgates = dgates.contiguous()
-        dx = dw = dbias = None
-        if ctx.needs_input_grad[3]:
-            dbias = dgates.sum(0)
-        if ctx.needs_input_grad[2]:
-            dw = torch.zeros_like(w)
-            for r0, r1 in _blocks(fdim):
-                ops.linear_dweight(dgates[:, r0:r1], x_flat, m=T, dw=dw[r0:r1])
-        if ctx.needs_input_grad[0]:
-            (a0, a1), (b0, b1) = _blocks(fdim)
-            tmp = torch.empty_like(x_flat)
-            ops.linear_dinput(dgates[:, a0:a1], w[a0:a1], m=T, out=tmp)
-            ops.linear_dinput(dgates[:, b0:b1], w[b0:b1], m=T, out=tmp, accumulate=True)
-            dx = torch.zeros((ctx.n_rows, fdim), dtype=torch.float32, device=x_flat.device)
-            dx.index_add_(0, idx, tmp.view(-1, fdim))
-        return dx, None, dw, dbias
-
-
 class _LstmGatesFn(Function):
-    """gates[t] = sum_j x[slots[j, t]] @ W_ih[:, jF:(j+1)F]^T + bias   (rows of the f gate: bias only)."""
+    """gates[t] = x_flat[t] @ W_ih^T   (rows of the f gate: zeros), nonempty[t] = target t has an in-edge."""
 
     @staticmethod
-    def forward(ctx, x, slots, w_ih, bias):
-        n_in, T = slots.shape
-        fdim = x.size(1)
+    def forward(ctx, x, w_ih, seg_ptr, src, node_map, num_targets, n_in):
+        T, fdim = int(num_targets), x.size(1)
         x = ops.aligned_rows(x)
-        # W_ih [4F, n_in*F] re-laid as [4F, n_in, ld] with 64-byte aligned segments (F = 602: ld 608)
-        ld = (fdim + 15) // 16 * 16
-        w_pad = torch.zeros((4 * fdim, n_in, ld), dtype=torch.float32, device=x.device)
-        w_pad[:, :, :fdim].copy_(w_ih.view(4 * fdim, n_in, fdim))
-        gates = torch.empty((T, 4 * fdim), dtype=torch.float32, device=x.device)
-        gates.copy_(bias.unsqueeze(0).expand(T, 4 * fdim))
+        x_flat = ops.empty_rows(T, n_in * fdim, x.device)
+        nonempty = torch.empty(T, dtype=torch.float32, device=x.device)
+        gates = ops.empty_rows(T, 4 * fdim, x.device, zero=True)
+        w = ops.aligned_rows(w_ih.detach())
         if T > 0:
-            for j in range(0, n_in, 2):
-                two = j + 1 < n_in
-                for r0, r1 in _blocks(fdim):
-                    ops.linear_concat_fwd(x, w_pad[r0:r1, j, :fdim], x if two else None,
-                                          w_pad[r0:r1, j + 1, :fdim] if two else None,
-                                          rows1=slots[j], rows2=slots[j + 1] if two else None, m=T,
-                                          out=gates[:, r0:r1], accumulate=True)
-        ctx.save_for_backward(x, slots, w_pad)
-        ctx.fdim = fdim
-        return gates
+            ops.lstm_gather_flat(x, seg_ptr, src, T, n_in, x_flat, nonempty, node_map=node_map)
+            for r0, r1 in _blocks(fdim):
+                ops.linear_concat_fwd(x_flat, w[r0:r1], m=T, out=gates[:, r0:r1])
+        ctx.save_for_backward(x_flat, w, seg_ptr, src)
+        ctx.fdim, ctx.n_in, ctx.n_rows, ctx.mapped = fdim, int(n_in), x.size(0), node_map is not None
+        ctx.mark_non_differentiable(nonempty)
+        return gates, nonempty
 
     @staticmethod
-    def backward(ctx, dgates):
-        x, slots, w_pad = ctx.saved_tensors
-        n_in, T = slots.shape
-        fdim = ctx.fdim
-        dgates = dgates.contiguous()
-        dx = dw = dbias = None
-        if ctx.needs_input_grad[3]:
-            dbias = dgates.sum(0)
-        if ctx.needs_input_grad[2]:
-            dw_pad = torch.zeros_like(w_pad)
+    def backward(ctx, dgates, _dnonempty):
+        x_flat, w, seg_ptr, src = ctx.saved_tensors
+        fdim, n_in, T = ctx.fdim, ctx.n_in, x_flat.size(0)
+        dgates = ops.aligned_rows(dgates.contiguous())
+        dx = dw = None
+        if ctx.needs_input_grad[1]:
+            dw = ops.empty_rows(4 * fdim, n_in * fdim, x_flat.device, zero=True)
             if T > 0:
-                for j in range(0, n_in, 2):
-                    for r0, r1 in _blocks(fdim):
-                        g = dgates[:, r0:r1]
-                        if j + 1 < n_in:
-                            ops.linear_dweight2(g, x, dw_pad[r0:r1, j, :fdim], x, dw_pad[r0:r1, j + 1, :fdim],
-                                                m=T, rows1=slots[j], rows2=slots[j + 1])
-                        else:
-                            ops.linear_dweight(g, x, m=T, rows=slots[j], dw=dw_pad[r0:r1, j, :fdim])
-            dw = dw_pad[:, :, :fdim].reshape(4 * fdim, n_in * fdim)
+                for r0, r1 in _blocks(fdim):
+                    ops.linear_dweight(dgates[:, r0:r1], x_flat, m=T, dw=dw[r0:r1])
         if ctx.needs_input_grad[0]:
-            dx = ops.empty_rows(x.size(0), fdim, x.device, zero=True)
+            if ctx.mapped:
+                raise RuntimeError("gradient w.r.t. a node_map'ed feature table is not supported")
+            dx = ops.empty_rows(ctx.n_rows, fdim, x_flat.device, zero=True)
             if T > 0:
-                # d x_flat [T, n_in * ld] in TWO contractions over all slots at once (the padded
-                # W_ih read as [4F, n_in * ld]: its pad columns are zeros), then one scatter per slot;
-                # per-slot contractions are 2 n_in launches of a 16-workgroup grid each (22 us apiece
-                # at T = 512)
-                ld = w_pad.size(2)
-                w_flat = w_pad.view(4 * fdim, n_in * ld)
-                tmp = ops.empty_rows(T, n_in * ld, x.device)
                 (a0, a1), (b0, b1) = _blocks(fdim)
-                ops.linear_dinput(dgates[:, a0:a1], w_flat[a0:a1], m=T, out=tmp)
-                ops.linear_dinput(dgates[:, b0:b1], w_flat[b0:b1], m=T, out=tmp, accumulate=True)
-                unit = torch.arange(T + 1, dtype=torch.int64, device=x.device)
-                for j in range(n_in):     # dx[slots[j, t]] += d x_flat[t, slot j]
-                    ops.gather_reduce_bwd(tmp[:, j * ld:j * ld + fdim], unit, slots[j], T, "sum", dx)
-        return dx, None, dw, dbias
+                d_flat = ops.empty_rows(T, n_in * fdim, x_flat.device)
+                ops.linear_dinput(dgates[:, a0:a1], w[a0:a1], m=T, out=d_flat)
+                ops.linear_dinput(dgates[:, b0:b1], w[b0:b1], m=T, out=d_flat, accumulate=True)
+                ops.lstm_scatter_flat(d_flat, seg_ptr, src, T, n_in, dx)
+        return dx, dw, None, None, None, None, None
 
 
 class _LstmCell0Fn(Function):
+    """h = cell(gates + b_ih + b_hh) from a zero state; the biases' gradient = column sums of d gates."""
+
     @staticmethod
-    def forward(ctx, gates, nonempty, num_features):
-        gates = gates.contiguous()
-        ctx.save_for_backward(gates, nonempty)
+    def forward(ctx, gates, nonempty, b_ih, b_hh, num_features):
+        ctx.save_for_backward(gates, nonempty, b_ih, b_hh)
         ctx.nf = int(num_features)
-        return ops.lstm_cell0_fwd(gates, nonempty, num_features)
+        return ops.lstm_cell0_fwd(gates, nonempty, num_features, bias_a=b_ih, bias_b=b_hh)
 
     @staticmethod
     def backward(ctx, dh):
-        gates, nonempty = ctx.saved_tensors
-        return ops.lstm_cell0_bwd(gates, nonempty, dh.contiguous(), ctx.nf), None, None
+        gates, nonempty, b_ih, b_hh = ctx.saved_tensors
+        dgates = ops.lstm_cell0_bwd(gates, nonempty, dh.contiguous(), ctx.nf, bias_a=b_ih, bias_b=b_hh)
+        dbias = dgates.sum(0) if (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]) else None
+        return dgates, None, dbias, dbias, None
 
 
 def lstm_aggregate(layer, x_src, plan, num_targets, node_map=None):
@@ -167,9 +106,6 @@ def lstm_aggregate(layer, x_src, plan, num_targets, node_map=None):
     fdim = x_src.size(1)
     if node_map is not None and x_src.requires_grad:
         raise RuntimeError("gradient w.r.t. a node_map'ed feature table is not supported")
-    slots, nonempty = ops.segment_slots(plan.seg_ptr, plan.src, num_targets, n_in, node_map=node_map)
-    bias = layer.lstm.bias_ih + layer.lstm.bias_hh
-    flat = (node_map is None and fdim % 16 == 0 and x_src.is_contiguous()
-            and 4 * num_targets * n_in * fdim <= _FLAT_BYTES)
-    gates = (_LstmGatesFlatFn if flat else _LstmGatesFn).apply(x_src, slots, layer.lstm.weight_ih, bias)
-    return _LstmCell0Fn.apply(gates, nonempty, fdim)
+    gates, nonempty = _LstmGatesFn.apply(x_src, layer.lstm.weight_ih, plan.seg_ptr, plan.src, node_map,
+                                         num_targets, n_in)
+    return _LstmCell0Fn.apply(gates, nonempty, layer.lstm.bias_ih, layer.lstm.bias_hh, fdim)

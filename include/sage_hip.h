@@ -74,6 +74,14 @@ typedef int64_t sage_i64;
 
 const char* sage_last_error(void);
 int sage_abi_version(void);
+/* Measurement hook (no counterpart in the reference; bench.py's roofline_mfma): an MFMA
+ * contraction kernel that this thread launches through sage_linear_concat_fwd /
+ * sage_pool_linear_fwd / sage_linear_dinput(2) / sage_linear_dweight(2) carries this HIP event
+ * pair (hipExtLaunchKernelGGL start / stop: their elapsed time is that dispatch's own duration)
+ * — the (skip+1)-th such launch from now.  One-shot per pair, at most 8 pending per thread
+ * (SAGE_ELIMIT); (NULL, NULL) cancels all pending pairs.  The skinny VALU kernels and the
+ * zero-fill launches do not count. */
+int sage_probe_next_contraction(void* start_event, void* stop_event, int skip);
 
 /* ------------------------------------------------------------------------------------
  * (a-1) CSC build.  Replaces torch_geometric.loader.utils.to_csc(data, device='cpu')

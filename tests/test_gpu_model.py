@@ -203,11 +203,11 @@ def test_ppi_shaped_multilabel_step_matches_oracle(dev):
     torch.testing.assert_close(full.cpu(), want, rtol=1e-4, atol=ATOL)
 
 
-@pytest.mark.parametrize("fin", [12, 32])
+@pytest.mark.parametrize("fin", [12, 32, 10, 7])
 def test_lstm_aggregator_matches_oracle(dev, fin):
     """a-7: parity unpinned against the reference (its lstm code is disabled as broken); the
-    kernels are checked against the oracle's well-defined restatement.  fin = 12: the K-segment
-    path through per-slot row maps; fin = 32: the materialised x_flat path of small target sets."""
+    kernels are checked against the oracle's well-defined restatement.  fin = 12 / 32: x_flat rows
+    of 48 / 128 floats (the 8- and 16-byte variants of sage_lstm_gather_flat's copies apply by F)."""
     from graphsage_amd.layers import SAGE
     n, e, fout, n_in = 120, 700, 8, 4
     ei = torch.from_numpy(random_graph(n, e, seed=8, isolated=5))
