@@ -97,6 +97,37 @@ def unsup_case(case, dims, feat_seed, layer_seed, lr=1e-2):
     return out
 
 
+def multilabel_case(case, dims, feat_seed, layer_seed, lr=1e-2):
+    """BASELINE configs[1] in small: the golden batch with multi-label targets (fp32 0 / 1, C
+    independent sigmoid outputs) and BCEWithLogitsLoss on the normalised logits of the seed rows
+    (reference examples/ppi_graphsage_supervised.py:30): loss, gradients, parameters after one
+    Adam step, and micro-F1's ingredients for the prediction y > 0
+    (graph_level_graphsage_trainers.py:57-58)."""
+    n = int(case["num_nodes"])
+    g = torch.Generator().manual_seed(feat_seed)
+    x = torch.randn(n, dims[0], generator=g)
+    y = (torch.rand(n, dims[-1], generator=g) < 0.4).float()
+    layers = make_layers(dims, "mean", layer_seed)
+    leaf = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
+    B = len(case["seeds"])
+    node = torch.from_numpy(case["node"].astype(np.int64))
+    ei = torch.from_numpy(np.stack([case["src"].astype(np.int64), case["dst"].astype(np.int64)]))
+    y_hat = sage_ref.graphsage_forward(x[node], ei, leaf, "mean")[:B]
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(y_hat, y[node[:B]])
+    loss.backward()
+    p_, t_ = y_hat.detach() > 0, y[node[:B]] > 0.5
+    out = dict(x=x.numpy(), y=y.numpy(), loss=np.float32(loss.detach()), y_hat=y_hat.detach().numpy(),
+               dims=np.array(dims, dtype=np.int64), lr=np.float32(lr),
+               stats=np.array([int((p_ & t_).sum()), int((p_ & ~t_).sum()), int((~p_ & t_).sum())], dtype=np.int64))
+    for i, (p, lf) in enumerate(zip(layers, leaf)):
+        for k in p:
+            out[f"w{i}_{k}"] = p[k].numpy()
+            out[f"g{i}_{k}"] = lf[k].grad.numpy()
+            new, _, _ = sage_ref.adam_ref(p[k], lf[k].grad, torch.zeros_like(p[k]), torch.zeros_like(p[k]), 1, lr)
+            out[f"a{i}_{k}"] = new.numpy()
+    return out
+
+
 def main():
     small = sampler_case(300, 2400, 5, 2, 40, [4, 3], graph_seed=5, rng_seed=21, counter=9, dup=True)
     np.savez_compressed(os.path.join(HERE, "sampler_small.npz"), **small)
@@ -111,6 +142,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"model_small_{agg}.npz"), **m)
     # same features / labels / weights as model_small_mean.npz (feat_seed 31, layer_seed 32)
     np.savez_compressed(os.path.join(HERE, "unsup_small.npz"), **unsup_case(small, [12, 8, 4], 31, 32))
+    np.savez_compressed(os.path.join(HERE, "multilabel_small.npz"), **multilabel_case(small, [12, 8, 70], 41, 42))
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")

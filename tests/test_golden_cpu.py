@@ -101,3 +101,27 @@ def test_oracle_unsup_step_reproduces_golden():
         for i, p in enumerate(layers):
             for k, v in p.items():
                 np.testing.assert_allclose(v.grad.numpy(), u[f"g_{tag}_{i}_{k}"], rtol=1e-4, atol=1e-7)
+
+
+def test_oracle_multilabel_step_reproduces_golden():
+    """multilabel_small.npz (BASELINE configs[1] in small): BCE-with-logits on the normalised
+    logits of the seed rows, its gradients, and the (tp, fp, fn) of the prediction y > 0."""
+    g = np.load(os.path.join(GOLD, "multilabel_small.npz"))
+    s = np.load(os.path.join(GOLD, "sampler_small.npz"))
+    layers = [{k[len(f"w{i}_"):]: torch.from_numpy(g[k]).clone().requires_grad_(True)
+               for k in g.files if k.startswith(f"w{i}_")} for i in range(2)]
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    node = torch.from_numpy(s["node"].astype(np.int64))
+    ei = torch.from_numpy(np.stack([s["src"].astype(np.int64), s["dst"].astype(np.int64)]))
+    B = len(s["seeds"])
+    y_hat = sage_ref.graphsage_forward(x[node], ei, layers, "mean")[:B]
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(y_hat, y[node[:B]])
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-6)
+    np.testing.assert_allclose(y_hat.detach().numpy(), g["y_hat"], rtol=1e-5, atol=1e-6)
+    for i, p in enumerate(layers):
+        for k, v in p.items():
+            np.testing.assert_allclose(v.grad.numpy(), g[f"g{i}_{k}"], rtol=1e-4, atol=1e-7)
+    p_, t_ = y_hat.detach() > 0, y[node[:B]] > 0.5
+    assert [int((p_ & t_).sum()), int((p_ & ~t_).sum()), int((~p_ & t_).sum())] == g["stats"].tolist()
+    assert set(np.unique(g["y"]).tolist()) == {0.0, 1.0} and g["y"].shape[1] == 70      # more outputs than one wave has lanes

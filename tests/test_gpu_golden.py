@@ -172,3 +172,42 @@ def test_engine_unsup_step_matches_golden(dev, unsup, tag):
                                    rtol=1e-3, atol=1e-6)
         np.testing.assert_allclose(engine.gviews[m.lin_r.weight].cpu().numpy(), u[f"g_{tag}_{i}_lin_r"],
                                    rtol=1e-3, atol=1e-6)
+
+
+def test_engine_multilabel_step_matches_golden(dev):
+    """multilabel_small.npz: the engine with fp32 [N, C] targets (sage_logits_bce_fused as the last
+    layer's loss; C = 70: more outputs than a wave has lanes) — sampled batch bit-exact, loss
+    rtol 1e-5, gradients rtol 1e-3, parameters after Adam, and evaluate()'s (tp, fp, fn)."""
+    from graphsage_amd.data import Data
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    g = np.load(os.path.join(GOLD, "multilabel_small.npz"))
+    s = np.load(os.path.join(GOLD, "sampler_small.npz"))
+    dims = g["dims"].tolist()
+    data = Data(x=torch.from_numpy(g["x"]), y=torch.from_numpy(g["y"]),
+                edge_index=torch.from_numpy(s["edge_index"].astype(np.int64)))
+    model = GraphSAGE(dims[0], dims[1], "mean", 2, dims[-1]).to(dev)
+    with torch.no_grad():
+        for i, m in enumerate(model.layers):
+            m.lin_l.weight.copy_(torch.from_numpy(g[f"w{i}_lin_l"]))
+            m.lin_r.weight.copy_(torch.from_numpy(g[f"w{i}_lin_r"]))
+    graph = device_graph(data)
+    B = len(s["seeds"])
+    seeds = torch.from_numpy(s["seeds"]).to(dev)
+    engine = SageTrainEngine(model, NeighborSampler(data, s["fanout"].tolist(), seed=int(s["rng_seed"])),
+                             graph.features(data), graph.labels(data), B, lr=float(g["lr"]), keep_grads=True)
+    assert engine.multilabel
+    # evaluation first (forward only, weights untouched): counter0 = the golden batch's counter
+    tp, fp, fn = engine.evaluate(seeds, counter0=int(s["counter"]))
+    assert [int(tp), int(fp), int(fn)] == g["stats"].tolist()
+    loss = engine.step(seeds, counter=int(s["counter"]))
+    nn = int(engine.buf.state[0])
+    assert engine.buf.node[:nn].cpu().numpy().tolist() == s["node"].tolist()
+    np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(engine.act[-1]['y'][:B].cpu().numpy(), g["y_hat"], rtol=1e-4, atol=2e-5)
+    for i, m in enumerate(model.layers):
+        for k, p in (("lin_l", m.lin_l.weight), ("lin_r", m.lin_r.weight)):
+            np.testing.assert_allclose(engine.gviews[p].cpu().numpy(), g[f"g{i}_{k}"], rtol=1e-3, atol=1e-6)
+            np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"a{i}_{k}"], rtol=1e-4, atol=1e-5)

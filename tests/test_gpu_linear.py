@@ -868,3 +868,92 @@ def test_l2norm_relu_bwd_z_matches_autograd(dev, m, n, relu):
     torch.testing.assert_close(dz[3].double().cpu(), ref3, rtol=1e-5, atol=0)
     assert bool((z_dev[:live] == 0).all()) and bool((dh_dev[:live] == 0).all())
     assert torch.equal(z_dev[live:].cpu(), z[live:]) and bool((dz[live:] == 9.0).all())   # beyond the device count: untouched
+
+
+@pytest.mark.parametrize("F_,n_in,mapped", [(602, 5, True), (256, 4, False), (10, 3, False), (7, 2, True)])
+def test_lstm_gather_scatter_flat_match_index_ops(dev, F_, n_in, mapped):
+    """sage_lstm_gather_flat / _scatter_flat (the lstm cell's flattened input, reference
+    layers/sage.py:164,:179, and its backward) against index arithmetic in torch: slot j of target t
+    = its j-th in-neighbour in edge order, its first one when it has fewer, zeros and nonempty = 0
+    without in-edges; through a node map; limited by a device-side target count; 16- / 8- / 4-byte
+    copies by what F allows."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(F_ + n_in)
+    rows, T = 300, 90
+    table = ops.empty_rows(rows, F_, dev)
+    table.copy_(torch.randn(rows, F_, generator=g))
+    deg = torch.randint(0, 9, (T,), generator=g)
+    deg[4] = 0
+    seg = torch.zeros(T + 1, dtype=torch.int64)
+    seg[1:] = deg.cumsum(0)
+    n_local = 120
+    src = torch.randint(0, n_local if mapped else rows, (int(seg[-1]),), generator=g)
+    node = torch.randperm(rows, generator=g)[:n_local] if mapped else None
+    live = T - 7
+    x_flat = ops.empty_rows(T, n_in * F_, dev)
+    x_flat.fill_(9.0)
+    nonempty = torch.full((T,), -1.0, device=dev)
+    ops.lstm_gather_flat(table, seg.to(dev), src.to(dev), T, n_in, x_flat, nonempty,
+                         node_map=node.to(dev) if mapped else None, num_targets_dev=torch.tensor([live], device=dev))
+    j = torch.arange(n_in).unsqueeze(0)
+    pos = seg[:-1].unsqueeze(1) + torch.where(j < deg.unsqueeze(1), j, torch.zeros_like(j))
+    ids = src[pos.clamp(max=max(src.numel() - 1, 0))]
+    if mapped:
+        ids = node[ids]
+    want = table.cpu()[ids.view(-1)].view(T, n_in * F_) * (deg > 0).float().unsqueeze(1)
+    assert torch.equal(x_flat[:live].cpu(), want[:live])                    # a copy: bit-exact
+    assert bool((x_flat[live:] == 9.0).all()) and bool((nonempty[live:] == -1.0).all())
+    assert torch.equal(nonempty[:live].cpu(), (deg[:live] > 0).float())
+    if not mapped:
+        d_flat = ops.empty_rows(T, n_in * F_, dev)
+        d_flat.copy_(torch.randn(T, n_in * F_, generator=g))
+        dx = ops.empty_rows(rows, F_, dev, zero=True)
+        ops.lstm_scatter_flat(d_flat, seg.to(dev), src.to(dev), T, n_in, dx, num_targets_dev=torch.tensor([live], device=dev))
+        ref = torch.zeros(rows, F_, dtype=torch.float64)
+        contrib = (d_flat.cpu().double() * (deg > 0).double().unsqueeze(1))[:live].reshape(-1, F_)
+        ref.index_add_(0, ids[:live].reshape(-1), contrib)
+        torch.testing.assert_close(dx.cpu().double(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("m,n", [(512, 121), (40, 70), (33, 7)])
+def test_logits_bce_fused_matches_torch(dev, m, n):
+    """sage_logits_bce_fused — normalise + BCEWithLogitsLoss + d loss / d z in one pass (reference
+    examples/ppi_graphsage_supervised.py:30 on SAGE's normalised outputs) — against torch autograd
+    in float64; per-row (tp, fp, fn); forward-only mode; z handed back zeroed."""
+    import torch.nn.functional as F
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(m + n)
+    N = 900
+    z = torch.randn(m, n, generator=g)
+    z[2] = 0.0                                     # the clamp's branch
+    targets = (torch.rand(N, n, generator=g) < 0.35).float()
+    rows = torch.randint(0, N, (m,), generator=g)
+    zr = z.double().clone().requires_grad_(True)
+    y_ref = F.normalize(zr, dim=-1)
+    loss_ref = F.binary_cross_entropy_with_logits(y_ref, targets[rows].double())
+    loss_ref.backward()
+    z_dev = ops.empty_rows(m, n, dev)
+    z_dev.copy_(z)
+    y = torch.zeros(m, n, device=dev)
+    dz = torch.zeros(m, n, device=dev)
+    row_loss = torch.zeros(m, device=dev)
+    loss = torch.zeros(1, device=dev)
+    stats = torch.zeros(m, 3, dtype=torch.int64, device=dev)
+    ops.logits_bce_fused(z_dev, targets.to(dev), rows.to(dev), m, y=y, dz=dz, row_loss=row_loss, loss=loss,
+                         row_stats=stats, clear_z=True)
+    torch.testing.assert_close(y.cpu().double(), y_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss.cpu().double().view(()), loss_ref.detach(), rtol=1e-5, atol=1e-7)
+    keep = [r for r in range(m) if r != 2]
+    torch.testing.assert_close(dz[keep].cpu().double(), zr.grad[keep], rtol=1e-4, atol=1e-8)
+    # the zero row: y = 0, gradient through the clamp = g / eps with g = (sigmoid(0) - t) / (m n)
+    want2 = (0.5 - targets[rows[2]].double()) / (m * n) * 1e12
+    torch.testing.assert_close(dz[2].cpu().double(), want2, rtol=1e-5, atol=0)
+    p_, t_ = y.cpu() > 0, targets[rows] > 0.5
+    want_stats = torch.stack([(p_ & t_).sum(1), (p_ & ~t_).sum(1), (~p_ & t_).sum(1)], dim=1)
+    assert torch.equal(stats.cpu(), want_stats)
+    assert bool((z_dev == 0).all())
+    # forward only: statistics without loss or gradient, z kept
+    z_dev.copy_(z)
+    stats2 = torch.zeros(m, 3, dtype=torch.int64, device=dev)
+    ops.logits_bce_fused(z_dev, targets.to(dev), rows.to(dev), m, row_stats=stats2)
+    assert torch.equal(stats2, stats) and torch.equal(z_dev.cpu(), z)
