@@ -284,6 +284,16 @@ class SageTrainEngine:
                         a['dxflat'] = padded(t_cap, n_in * fin)
                 if i > 0 or self.pool or self.lstm:
                     a['dagg'] = padded(t_cap, fin)
+                    if (self.lstm and i == 0 and t_cap >= 4096 and fin >= 256
+                            and not os.environ.get('SAGE_NO_DAGG_X3')):
+                        # layer 0's d agg = dz . W_l as a FORWARD-type contraction on a transposed copy
+                        # of W_l (both operands contiguous in the contracted index: the bf16x3 kernel
+                        # takes it; the d-input kernel is exact-fp32 only, 69 us at the Reddit shape):
+                        # lstm 9.12 against 9.18 ms per step.  Not for the pooling aggregators: there
+                        # this contraction runs beside the forked weight gradients and the same-box A/B
+                        # went the other way (max_pool 1.209 against 1.200 ms, mean_pool 1.310 / 1.307;
+                        # scratch/dagg_ab.sh) — VERDICT r2 item 6's first half, measured and not kept
+                        a['wlT'] = padded(fin, fout)
                     if self.reduce == 'max':   # the backward routes to the edge that attained the max
                         a['argmax'] = torch.zeros((t_cap, fin), dtype=torch.int64, device=dev)
                 if self.pool:
@@ -561,7 +571,7 @@ class SageTrainEngine:
             ops.linear_dinput2(a['dz'], layer.lin_r.weight, self.act[i - 1]['dh'], layer.lin_l.weight, a['dagg'],
                                m=t_cap, m_dev=t_dev)
         else:
-            ops.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
+            self._dagg_layer0(slot)
         ops.lstm_cell0_bwd(a['gates'], a['nonempty'], a['dagg'], fdim, m=t_cap, m_dev=t_dev,
                            bias_a=layer.lstm.bias_ih, bias_b=layer.lstm.bias_hh, out=a['dgates'])
         gw, gb_ih, gb_hh = (self.gviews[p] for p in (layer.lstm.weight_ih, layer.lstm.bias_ih, layer.lstm.bias_hh))
@@ -765,6 +775,17 @@ class SageTrainEngine:
             torch.cuda.set_stream(main)
         self._forked = True
 
+    def _dagg_layer0(self, slot):
+        """d agg of layer 0 = dz . W_l (the aggregate path of the pooling / lstm backward)."""
+        a, layer = self.act[0], self.model.layers[0]
+        t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
+        if 'wlT' in a:
+            wt, w = a['wlT'], layer.lin_l.weight
+            _lib.tape_py(lambda: wt.copy_(w.t()))
+            ops.linear_concat_fwd(a['dz'], wt, m=t_cap, m_dev=t_dev, out=a['dagg'])
+        else:
+            ops.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
+
     def _pool_backward(self, slot, i, x_in, rows):
         """Layer i's aggregate path with a pooling aggregator: d agg -> (through the reduce) d P ->
         (relu) d pool(x) -> pool weight / bias gradients and, above layer 0, the input gradient."""
@@ -775,7 +796,7 @@ class SageTrainEngine:
             lib.linear_dinput2(a['dz'], layer.lin_r.weight, self.act[i - 1]['dh'], layer.lin_l.weight, a['dagg'],
                                m=t_cap, m_dev=t_dev)
         else:
-            lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
+            self._dagg_layer0(slot)
         # the in-degree workspace (two short launches) pays for itself on the 13k targets of layer
         # 0; the B seed rows of the layers above are routed with atomics throughout
         # (max_pool 1.199 against 1.212 ms per step, mean_pool unchanged; scratch/pool_indeg_ab.sh)
