@@ -334,6 +334,7 @@ class SageTrainEngine:
         self.use_tapes = True   # False: every call goes through the validating wrappers of ops.py (measurement hooks)
         self._pending = PendingReduce()   # data parallel: the gradient all-reduce not yet applied
         self.trace = None       # tests: a list that receives the name of every piece of a step as it is ENQUEUED
+        self._side_first = bool(os.environ.get('SAGE_SIDE_FIRST'))   # A/B: the round-2 enqueue order
         # data parallel: the host may run at most `run_ahead` steps (= un-waited collectives)
         # ahead of the device: it blocks on the event recorded that many steps ago
         self.run_ahead = 8
@@ -947,17 +948,18 @@ class SageTrainEngine:
         p = i % self.nslots
         ov = self.overlap_gather
         main = torch.cuda.current_stream()
+        main_first = not self._side_first
+        side_next = False
         if ov:
             if not self.gathered[p]:      # pipeline was drained below its depth
                 self._side_gather(p, None, None)
                 self.ready[p].record(self.side)
             main.wait_event(self.ready[p])
-            if self.n_pref - i > 1:
+            side_next = self.n_pref - i > 1
+            if side_next:
                 self.started.record(main)
-                self.side.wait_event(self.started)
-                q = (i + 1) % self.nslots
-                self._side_gather(q, before_gather, after_gather, gather_events)
-                self.ready[q].record(self.side)
+                if not main_first:
+                    self._gather_next(i, before_gather, after_gather, gather_events)
         else:
             if i > self.main_ready_seq:
                 # one wait covers every batch prefetched so far (the side stream is in order)
@@ -975,7 +977,7 @@ class SageTrainEngine:
             if after_gather is not None:
                 after_gather()
         self.n_comp = i + 1
-        if next_seeds is not None:
+        if next_seeds is not None and not main_first:
             self.prefetch(next_seeds, next_counter, _in_step=True)
         # data parallel: the previous step's all-reduce has been running on the collective's own
         # stream while this step's sampler wait and (weight-free) layer-0 gather were enqueued;
@@ -1001,11 +1003,30 @@ class SageTrainEngine:
                     self._dp_events.pop(0).synchronize()
         else:
             self.optimizer_step()
+        if main_first:
+            # the side streams' share of this call LAST: when the host is not ahead of the device
+            # (the first step behind a synchronisation — a 20-step timing window starts with one —
+            # or a host-bound loop), the main stream's kernels then reach the device ~0.1 ms
+            # earlier; the gather is still held back by `started`, recorded in front of them.
+            # (In front of this step's cons_ev record: the sampler of batch i+depth waits for the
+            # compute of the batch that used its slot, not for this one.)
+            if ov and side_next:
+                self._gather_next(i, before_gather, after_gather, gather_events)
+            if next_seeds is not None:
+                self.prefetch(next_seeds, next_counter)
         if (i + 1) % self.group == 0:
             ev = self.cons_ev[(i // self.group) & 1]
             ev.record(main)
             self.cons_latest, self.cons_rec_seq = ev, i
         return self.loss
+
+    def _gather_next(self, i, before_gather, after_gather, gather_events):
+        """overlap_gather: the layer-0 gather of batch i+1 on the side stream, released when the main
+        stream has reached the start of step i (`started`)."""
+        self.side.wait_event(self.started)
+        q = (i + 1) % self.nslots
+        self._side_gather(q, before_gather, after_gather, gather_events)
+        self.ready[q].record(self.side)
 
     def _infer_batch(self, slot, pred):
         """Forward of the batch in `slot` (its layer-0 aggregate is in place) down to the arg-max
