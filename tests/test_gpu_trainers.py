@@ -382,3 +382,41 @@ def test_fig2b_reported_f1_matches_oracle(dev):
     test_ids = data.test_mask.nonzero().view(-1)
     f1_ref = _oracle_accuracy(data, params, test_ids, [s, s], seed, 0, B)     # test loader's first pass: epoch 0
     assert abs(out['test_f1'] - f1_ref) <= 0.005, (out['test_f1'], f1_ref)
+
+
+def test_engine_evaluation_is_what_fig2a_and_the_trainers_call(dev, monkeypatch):
+    """fig2a.test() and the supervised trainer's eval() run the engine's forward-only pipeline over
+    the loader's seeds (engine.evaluate_loader) — not the module path — whenever they hold an
+    engine; the loader's epoch advances by the two passes the reference makes per evaluation
+    (inference, then labels: trainers/node_level_graphsage_trainers.py:54-55)."""
+    import torch.nn.functional as F
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.experiments import fig2a
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import UniformLoader
+    from graphsage_amd.trainers import SupervisedGraphSageTrainerForNodeLevelTask, dataloader_kwargs
+    calls = []
+    real = SageTrainEngine.evaluate_loader
+
+    def spy(self, loader, return_pred=False):
+        out = real(self, loader, return_pred)
+        calls.append(out is not None)
+        return out
+    monkeypatch.setattr(SageTrainEngine, "evaluate_loader", spy)
+    monkeypatch.setattr(GraphSAGE, "inference", lambda self, loader: (_ for _ in ()).throw(AssertionError("module path taken")))
+    ds = _dataset(noise=1.0)
+    out = fig2a.get("mean", dataset=ds, num_epochs=2, batch_size=128, k1=6, k2=4, verbose=False).run()
+    assert out['engine'] and calls == [True, True] and out['test_acc'] > 0.5
+    calls.clear()
+    data = ds[0]
+    torch.manual_seed(0)
+    model = GraphSAGE(ds.num_features, 32, "mean", 2, ds.num_classes).to(dev)
+    monkeypatch.setitem(dataloader_kwargs, 'batch_size', 128)
+    tr = SupervisedGraphSageTrainerForNodeLevelTask(data, UniformLoader, supervised_only=True, loss_fn=F.cross_entropy,
+                                                    model=model, optimizer=torch.optim.Adam(model.parameters(), lr=1e-2),
+                                                    num_epochs=1, device=dev, k1=6, k2=4)
+    assert tr.engine is not None
+    e0 = tr.test_loader.epoch
+    res = tr.test()
+    assert calls and all(calls) and tr.test_loader.epoch == e0 + 2
+    assert 0.0 <= res['test_f1'] <= 1.0 and res['test_acc'] == res['test_f1']
