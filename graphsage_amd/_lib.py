@@ -59,6 +59,8 @@ SIGNATURES = {
     "sage_lstm_cell0_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, _P, _P, c_int64, _P]),
     "sage_lstm_cell0_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int, _P, _P, _P, c_int64, _P]),
     "sage_lstm_gather_flat": (c_int, [_P, c_int64, _P, _P, _P, c_int64, _P, c_int, c_int, _P, c_int64, _P, _P]),
+    "sage_lstm_pad_weight_sum": (c_int, [_P, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, _P]),
+    "sage_lstm_pad_grad_bcast": (c_int, [_P, c_int64, c_int64, c_int, c_int, c_int, _P, c_int64, _P]),
     "sage_lstm_scatter_flat": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, c_int, _P, c_int64, _P]),
     "sage_l2norm_relu_fwd": (c_int, [_P, c_int64, c_int64, _P, c_int, _P, c_int64, _P, c_int64,
                                      _P, c_int, _P]),

@@ -155,10 +155,73 @@ lstm_scatter_flat_kernel(const float* __restrict__ dflat, int64_t ld_flat, const
   }
 }
 
+// Targets whose segments are SHORTER than n_in by construction (the rows behind the seeds in a
+// sampled batch: their edges come from a hop with a smaller fan-out k) repeat their first
+// neighbour in slots k .. n_in-1, so for them
+//     x_flat[t] . W_ih^T = sum_{j<k} x_j . W_j^T  +  x_0 . (sum_{j>=k} W_j)^T
+// (W_j = columns j F .. (j+1) F of W_ih): the padded slots cost one slot's flops instead of
+// n_in - k.  out[r, f] = sum_{j0 <= j < j1} w[r, j F + f], summed in slot order.
+__global__ void __launch_bounds__(kBlock)
+lstm_pad_weight_sum_kernel(const float* __restrict__ w, int64_t ld_w, int64_t rows, int F, int j0, int j1,
+                           float* __restrict__ out, int64_t ld_out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= rows * F) return;
+  const int64_t r = i / F;
+  const int f = static_cast<int>(i - r * F);
+  const float* wr = w + r * ld_w + f;
+  float s = 0.f;
+  for (int j = j0; j < j1; ++j) s += wr[static_cast<int64_t>(j) * F];
+  out[r * ld_out + f] = s;
+}
+
+// ... and the backward of that sum: every padded slot's weight gradient receives the gradient of
+// the summed block, dw[r, j F + f] += g[r, f] for j0 <= j < j1; g is handed back zeroed (the weight
+// gradient kernels accumulate into it).
+__global__ void __launch_bounds__(kBlock)
+lstm_pad_grad_bcast_kernel(float* __restrict__ g, int64_t ld_g, int64_t rows, int F, int j0, int j1,
+                           float* __restrict__ dw, int64_t ld_dw) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= rows * F) return;
+  const int64_t r = i / F;
+  const int f = static_cast<int>(i - r * F);
+  const float v = g[r * ld_g + f];
+  g[r * ld_g + f] = 0.f;
+  float* dr = dw + r * ld_dw + f;
+  for (int j = j0; j < j1; ++j) dr[static_cast<int64_t>(j) * F] += v;
+}
+
 }  // namespace
 }  // namespace sage
 
 using namespace sage;
+
+extern "C" int sage_lstm_pad_weight_sum(const float* w, sage_i64 ld_w, sage_i64 rows, int num_features, int j0, int j1,
+                                        float* out, sage_i64 ld_out, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(rows >= 0 && num_features > 0 && 0 <= j0 && j0 <= j1 && ld_w >= static_cast<int64_t>(j1) * num_features &&
+                   ld_out >= num_features,
+               SAGE_EINVAL, "sage_lstm_pad_weight_sum: bad sizes");
+  if (rows == 0) return SAGE_OK;
+  SAGE_REQUIRE(w && out, SAGE_EINVAL, "sage_lstm_pad_weight_sum: NULL pointer argument");
+  lstm_pad_weight_sum_kernel<<<static_cast<unsigned>(cdiv(rows * num_features, kBlock)), kBlock, 0, stream>>>(
+      w, ld_w, rows, num_features, j0, j1, out, ld_out);
+  SAGE_CHECK_LAUNCH("lstm_pad_weight_sum_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_lstm_pad_grad_bcast(float* g, sage_i64 ld_g, sage_i64 rows, int num_features, int j0, int j1,
+                                        float* dw, sage_i64 ld_dw, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(rows >= 0 && num_features > 0 && 0 <= j0 && j0 <= j1 && ld_dw >= static_cast<int64_t>(j1) * num_features &&
+                   ld_g >= num_features,
+               SAGE_EINVAL, "sage_lstm_pad_grad_bcast: bad sizes");
+  if (rows == 0) return SAGE_OK;
+  SAGE_REQUIRE(g && dw, SAGE_EINVAL, "sage_lstm_pad_grad_bcast: NULL pointer argument");
+  lstm_pad_grad_bcast_kernel<<<static_cast<unsigned>(cdiv(rows * num_features, kBlock)), kBlock, 0, stream>>>(
+      g, ld_g, rows, num_features, j0, j1, dw, ld_dw);
+  SAGE_CHECK_LAUNCH("lstm_pad_grad_bcast_kernel");
+  return SAGE_OK;
+}
 
 extern "C" int sage_lstm_gather_flat(const float* x, sage_i64 ld_x, const sage_i64* node_map,
                                      const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,

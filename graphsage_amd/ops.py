@@ -1025,3 +1025,30 @@ def lstm_scatter_flat(d_flat, seg_ptr, src, num_targets, n_in, dx, num_targets_d
                                     _count(num_targets_dev, "num_targets_dev"), int(n_in), F, xp, ld_dx, _stream())
     _lib.check(rc, "sage_lstm_scatter_flat")
     return dx
+
+
+def lstm_pad_weight_sum(w, num_features, j0, j1, out):
+    """out[r, f] = sum_{j0<=j<j1} w[r, j*F + f]: the weights every padded slot of a short segment
+    shares (see sage_hip.h, sage_lstm_pad_weight_sum)."""
+    lib = _lib.load()
+    wp, ld_w = _mat(w, "w")
+    op, ld_o = _mat(out, "out")
+    F = int(num_features)
+    if w.size(1) < j1 * F or out.size(0) != w.size(0) or out.size(1) != F or not 0 <= j0 <= j1:
+        raise RuntimeError("lstm_pad_weight_sum: shape mismatch")
+    rc = lib.sage_lstm_pad_weight_sum(wp, ld_w, w.size(0), F, int(j0), int(j1), op, ld_o, _stream())
+    _lib.check(rc, "sage_lstm_pad_weight_sum")
+    return out
+
+
+def lstm_pad_grad_bcast(g, num_features, j0, j1, dw):
+    """dw[r, j*F + f] += g[r, f] for j0<=j<j1; g comes back zeroed."""
+    lib = _lib.load()
+    gp, ld_g = _mat(g, "g")
+    dp, ld_d = _mat(dw, "dw")
+    F = int(num_features)
+    if dw.size(1) < j1 * F or g.size(0) != dw.size(0) or g.size(1) != F or not 0 <= j0 <= j1:
+        raise RuntimeError("lstm_pad_grad_bcast: shape mismatch")
+    rc = lib.sage_lstm_pad_grad_bcast(gp, ld_g, dw.size(0), F, int(j0), int(j1), dp, ld_d, _stream())
+    _lib.check(rc, "sage_lstm_pad_grad_bcast")
+    return dw

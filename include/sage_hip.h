@@ -377,6 +377,19 @@ int sage_lstm_gather_flat(const float* x, sage_i64 ld_x, const sage_i64* node_ma
 int sage_lstm_scatter_flat(const float* d_flat, sage_i64 ld_flat, const sage_i64* seg_ptr,
                            const sage_i64* src, sage_i64 num_targets, const sage_i64* num_targets_dev,
                            int n_in, int num_features, float* dx, sage_i64 ld_dx, void* stream);
+/* Padded slots (layers/sage.py:164: a target with fewer than n_in neighbours repeats its FIRST one).
+ * The rows behind the seeds of a sampled batch have at most k < n_in neighbours by construction
+ * (their edges come from a hop with fan-out k), so for them slots k .. n_in-1 all hold the first
+ * neighbour's row and
+ *     x_flat[t] . W_ih^T = sum_{j<k} x_j . W_j^T + x_0 . (sum_{j>=k} W_j)^T,   W_j = W_ih[:, jF:(j+1)F]:
+ * the engine contracts those rows over k+1 slots instead of n_in (the same sum, re-associated).
+ *   sage_lstm_pad_weight_sum:  out[r, f] = sum_{j0<=j<j1} w[r, jF + f]      (slot order, rows x F)
+ *   sage_lstm_pad_grad_bcast:  dw[r, jF + f] += g[r, f] for j0<=j<j1, then g[r, f] = 0
+ *     (the backward of that sum; g is the weight gradient against the summed block). */
+int sage_lstm_pad_weight_sum(const float* w, sage_i64 ld_w, sage_i64 rows, int num_features, int j0, int j1,
+                             float* out, sage_i64 ld_out, void* stream);
+int sage_lstm_pad_grad_bcast(float* g, sage_i64 ld_g, sage_i64 rows, int num_features, int j0, int j1,
+                             float* dw, sage_i64 ld_dw, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Row-wise epilogues of the layer and the loss.

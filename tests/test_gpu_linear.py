@@ -915,6 +915,34 @@ def test_lstm_gather_scatter_flat_match_index_ops(dev, F_, n_in, mapped):
         torch.testing.assert_close(dx.cpu().double(), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("F_,n_in,j0", [(602, 25, 10), (40, 4, 3), (7, 5, 0), (16, 3, 3)])
+def test_lstm_pad_weight_sum_and_grad_bcast(dev, F_, n_in, j0):
+    """sage_lstm_pad_weight_sum / _pad_grad_bcast: the slots j0 .. n_in-1 of a segment shorter than
+    j0 all hold the first neighbour (reference layers/sage.py:164), so they contract against the sum
+    of their weight blocks, and that sum's gradient goes back to every one of the blocks."""
+    from graphsage_amd import ops
+    g = torch.Generator().manual_seed(F_ * n_in + j0)
+    R = 4 * F_
+    w = ops.empty_rows(R, n_in * F_, dev)
+    w.copy_(torch.randn(R, n_in * F_, generator=g))
+    out = ops.empty_rows(R, F_, dev)
+    out.fill_(5.0)
+    ops.lstm_pad_weight_sum(w, F_, j0, n_in, out)
+    want = w.cpu().double().view(R, n_in, F_)[:, j0:].sum(1)
+    torch.testing.assert_close(out.cpu().double(), want, rtol=1e-6, atol=1e-6)
+    gp = ops.empty_rows(R, F_, dev)
+    gp.copy_(torch.randn(R, F_, generator=g))
+    dw = ops.empty_rows(R, n_in * F_, dev)
+    dw.copy_(torch.randn(R, n_in * F_, generator=g))
+    ref = dw.cpu().clone().view(R, n_in, F_)
+    ref[:, j0:] += gp.cpu().unsqueeze(1)
+    ops.lstm_pad_grad_bcast(gp, F_, j0, n_in, dw)
+    assert torch.equal(dw.cpu().view(R, n_in, F_), ref)         # one add per element: bit-exact
+    assert bool((gp == 0).all())                                # handed back zeroed for the next step
+    with pytest.raises(RuntimeError):
+        ops.lstm_pad_weight_sum(w, F_, 0, n_in + 1, out)
+
+
 @pytest.mark.parametrize("m,n", [(512, 121), (40, 70), (33, 7)])
 def test_logits_bce_fused_matches_torch(dev, m, n):
     """sage_logits_bce_fused — normalise + BCEWithLogitsLoss + d loss / d z in one pass (reference
