@@ -288,7 +288,7 @@ class SageTrainEngine:
                     # against the sum of those slots' weight blocks: kpad + 1 slot-products instead of
                     # n_in for 96 % of the Reddit batch's targets (k2 = 10, n_in = 25).  Layer 0 only
                     # (no input gradient there); SAGE_LSTM_NO_PADSUM=1 keeps the full contraction.
-                    kpad = max(fan[1:]) if len(fan) > 1 else n_in
+                    kpad = max(fan[1:]) if len(fan) > 1 and min(fan[1:]) >= 0 else n_in   # (-1 = every neighbour)
                     if (i == 0 and t_cap > self.B and kpad < n_in and not os.environ.get('SAGE_LSTM_NO_PADSUM')):
                         a['kpad'] = kpad
                         a['wsum'] = padded(4 * fin, fin)          # sum of the padded slots' weight blocks
@@ -567,16 +567,20 @@ class SageTrainEngine:
         """agg[t] = LSTMCell(x_flat[t]) from a zero state for the layer's targets."""
         a, layer, buf = self.act[i], self.model.layers[i], self.bufs[slot]
         t_cap, t_dev, fdim = a['t_cap'], self.n_dev[slot][a['hop']], a['fin']
-        ops.lstm_gather_flat(x, buf.seg_ptr, buf.src, t_cap, a['n_in'], a['xflat'], a['nonempty'],
-                             node_map=node_map, num_targets_dev=t_dev)
         w = layer.lstm.weight_ih
         kp = a.get('kpad')
         if kp is None:
+            ops.lstm_gather_flat(x, buf.seg_ptr, buf.src, t_cap, a['n_in'], a['xflat'], a['nonempty'],
+                                 node_map=node_map, num_targets_dev=t_dev)
             for r0, r1 in self._lstm_blocks(fdim):
                 ops.linear_concat_fwd(a['xflat'], w[r0:r1], m=t_cap, m_dev=t_dev, out=a['gates'][:, r0:r1])
         else:
             B, rest_dev, xf = self.B, a['rest_dev'], a['xflat']
             _lib.tape_py(lambda: torch.sub(t_dev, B, out=rest_dev))
+            # (slots kp .. n_in-1 of the rows behind the seeds are never read: not written either)
+            ops.lstm_gather_flat(x, buf.seg_ptr, buf.src, B, a['n_in'], xf, a['nonempty'], node_map=node_map)
+            ops.lstm_gather_flat(x, buf.seg_ptr[B:], buf.src, t_cap - B, kp, xf[B:, :kp * fdim], a['nonempty'][B:],
+                                 node_map=node_map, num_targets_dev=rest_dev)
             ops.lstm_pad_weight_sum(w, fdim, kp, a['n_in'], a['wsum'])
             for r0, r1 in self._lstm_blocks(fdim):
                 # the seeds: up to n_in real neighbours, the full contraction

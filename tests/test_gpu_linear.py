@@ -929,7 +929,7 @@ def test_lstm_pad_weight_sum_and_grad_bcast(dev, F_, n_in, j0):
     out.fill_(5.0)
     ops.lstm_pad_weight_sum(w, F_, j0, n_in, out)
     want = w.cpu().double().view(R, n_in, F_)[:, j0:].sum(1)
-    torch.testing.assert_close(out.cpu().double(), want, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(out.cpu().double(), want, rtol=1e-5, atol=5e-6)      # fp32 sums of up to 15 terms
     gp = ops.empty_rows(R, F_, dev)
     gp.copy_(torch.randn(R, F_, generator=g))
     dw = ops.empty_rows(R, n_in * F_, dev)
