@@ -288,7 +288,7 @@ class SageTrainEngine:
                     # against the sum of those slots' weight blocks: kpad + 1 slot-products instead of
                     # n_in for 96 % of the Reddit batch's targets (k2 = 10, n_in = 25).  Layer 0 only
                     # (no input gradient there); SAGE_LSTM_NO_PADSUM=1 keeps the full contraction.
-                    kpad = max(fan[1:]) if len(fan) > 1 and min(fan[1:]) >= 0 else n_in   # (-1 = every neighbour)
+                    kpad = max(fan[1:]) if len(fan) > 1 else n_in      # (fan-outs are non-negative here)
                     if (i == 0 and t_cap > self.B and kpad < n_in and not os.environ.get('SAGE_LSTM_NO_PADSUM')):
                         a['kpad'] = kpad
                         a['wsum'] = padded(4 * fin, fin)          # sum of the padded slots' weight blocks

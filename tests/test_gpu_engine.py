@@ -53,6 +53,44 @@ def test_engine_matches_module_path(dev, aggregator, monkeypatch):
     assert int(engine.step_dev) == 4
 
 
+@pytest.mark.parametrize("fanout,n_in,padsum", [([4, 2, 3], 6, True), ([6, 4], 4, False), ([3, 5], 4, False)])
+def test_lstm_engine_padded_slot_split(dev, fanout, n_in, padsum, monkeypatch):
+    """lstm layer 0 on the engine: the rows behind the seeds contract their padded slots once
+    (engine.make_act `kpad`, csrc/lstm.hip `lstm_pad_weight_sum_kernel`) — three hops (kpad = the
+    largest of the later fan-outs), and the cases that must NOT take the split (later fan-outs at or
+    above LSTM_NUM_INPUTS) — each against the module path's
+    gradients (reference layers/sage.py:147-193 as read in layers/lstm.py)."""
+    from graphsage_amd import settings
+    from graphsage_amd.datasets import planted_partition
+    monkeypatch.setattr(settings, "LSTM_NUM_INPUTS", n_in)
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler, UniformLoader
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = planted_partition(1500, 18000, 24, 5, seed=11)
+    B, L = 32, len(fanout)
+    loader = UniformLoader(data, num_neighbors=fanout, input_nodes=torch.arange(3 * B), batch_size=B, seed=3)
+    torch.manual_seed(1)
+    model_a = GraphSAGE(24, 16, "lstm", L, 5).to(dev)
+    model_b = copy.deepcopy(model_a)
+    graph = device_graph(data)
+    engine = SageTrainEngine(model_b, NeighborSampler(data, fanout, seed=3), graph.features(data),
+                             graph.labels(data), B, lr=1e-2, keep_grads=True)
+    assert ('kpad' in engine.act[0]) == padsum
+    if padsum:
+        assert engine.act[0]['kpad'] == max(fanout[1:]) and all('kpad' not in a for a in engine.act[1:])
+    for b, batch in enumerate(loader):
+        model_a.zero_grad()
+        loss_a = F.cross_entropy(model_a.forward_batch(batch), batch.y[:B])
+        loss_a.backward()
+        loss_b = engine.step(torch.arange(b * B, (b + 1) * B, device=dev), counter=b)
+        torch.testing.assert_close(loss_b[0], loss_a.detach(), rtol=1e-5, atol=1e-6)
+        for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+            ga = pa.grad if pa.grad is not None else torch.zeros_like(pa)
+            torch.testing.assert_close(engine.gviews[pb], ga, rtol=1e-3, atol=1e-6)
+            pa.data.copy_(pb.data)          # same weights for the next batch (Adam ran on the engine only)
+
+
 @pytest.mark.parametrize("split", [False, True])
 def test_graph_replay_matches_eager_steps(dev, split, overlap=False):
     """HIP-graph replay (device control block drives seeds / Philox counter / stamp) runs the
