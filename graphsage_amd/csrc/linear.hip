@@ -1597,7 +1597,11 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
     const bool fill128 = slots > 0 && !(bm_env && bm_env[0] == '6') &&
                          (t128 >= 2ll * slots || t128 * 10 >= cdiv(t128, slots) * slots * 9 ||
                           (t128 > slots && t128 % slots * 100 <= 3 * slots && m_dev != nullptr));
-    const bool whole = tiles >= 8 * grid_x3 || !plain || cdiv(k1, BK) + cdiv(k2, BK) <= 12 || fill128;
+    // SAGE_FWD_WHOLE=64 / 128: whole tiles of that many rows whatever the rule says (the A/B switch
+    // of DESIGN.md 8.0: the headline forward without stream-K's atomic epilogue)
+    static const char* whole_env = getenv("SAGE_FWD_WHOLE");
+    const bool force128 = whole_env && whole_env[0] == '1';
+    const bool whole = tiles >= 8 * grid_x3 || !plain || cdiv(k1, BK) + cdiv(k2, BK) <= 12 || fill128 || whole_env;
     if (x3_mode() && (plain || whole) && n > 64 && slots > 0 && vec4 && steps >= 6ll * slots) {
       if (whole) {
         g.whole = 1;
@@ -1607,7 +1611,7 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
         SAGE_CHECK_LAUNCH("zero_rows_kernel");
       }
       g.xcd_map = xcd_mode() ? 1 : 0;
-      if (whole && fill128) {
+      if (whole && (whole_env ? force128 : fill128)) {
         SAGE_LAUNCH_PROBED((gemm_x3_kernel<128>), static_cast<unsigned>(slots), kThreads, stream, g);
       } else {
         SAGE_LAUNCH_PROBED((gemm_x3_kernel<64>), static_cast<unsigned>(grid_x3), kThreads, stream, g);
