@@ -14,6 +14,7 @@
 //     and loss = mean(row_loss), reduced by the first wave in a fixed order.
 // The weight gradients stay with sage_linear_dweight2 (they need agg, which the forward keeps).
 #include "common.h"
+#include "skinny_dw.h"
 
 #include <mutex>
 #include <type_traits>
@@ -377,12 +378,12 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
 
 // NC = H / 64 (a lane owns columns lane + 64 k)
 template <int NC, bool FULL>      // FULL: h == 64 NC
-__global__ void __launch_bounds__(kLogitBlock)
-logit_bwd_kernel(const float* __restrict__ dz, int64_t ld_dz, const int64_t* __restrict__ seg_ptr,
-                 const int64_t* __restrict__ src, int64_t m, int h, int mean,
-                 const float* __restrict__ w_l, int64_t ld_wl, const float* __restrict__ w_r, int64_t ld_wr,
-                 int n, float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ row_loss,
-                 float* __restrict__ loss) {
+__device__ __forceinline__ void
+logit_bwd_body(const float* __restrict__ dz, int64_t ld_dz, const int64_t* __restrict__ seg_ptr,
+               const int64_t* __restrict__ src, int64_t m, int h, int mean,
+               const float* __restrict__ w_l, int64_t ld_wl, const float* __restrict__ w_r, int64_t ld_wr,
+               int n, float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ row_loss,
+               float* __restrict__ loss) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
@@ -462,6 +463,43 @@ logit_bwd_kernel(const float* __restrict__ dz, int64_t ld_dz, const int64_t* __r
   LOGIT_STAMP(1, 4);
 }
 
+template <int NC, bool FULL>
+__global__ void __launch_bounds__(kLogitBlock)
+logit_bwd_kernel(const float* __restrict__ dz, int64_t ld_dz, const int64_t* __restrict__ seg_ptr,
+                 const int64_t* __restrict__ src, int64_t m, int h, int mean,
+                 const float* __restrict__ w_l, int64_t ld_wl, const float* __restrict__ w_r, int64_t ld_wr,
+                 int n, float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ row_loss,
+                 float* __restrict__ loss) {
+  logit_bwd_body<NC, FULL>(dz, ld_dz, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, dh, ld_dh, row_loss, loss);
+}
+
+// The same launch with the layer's two weight gradients riding along: workgroups 0 .. seed_blocks-1
+// are the seeds' (above), the ones behind them run skinny_dweight_body (dW_l += dz^T agg,
+// dW_r += dz^T h_root) — 128 seed workgroups leave half of the CUs idle, and both halves read
+// nothing the other writes.  (The weights' LDS image is allocated for every workgroup of the
+// launch: one workgroup per CU.)
+struct LogitDwArgs {
+  SkinnyDwProblem p0, p1;
+  int slices, m_chunk, gx, gy;
+  const int64_t* m_dev;
+};
+template <int NC, bool FULL>
+__global__ void __launch_bounds__(kLogitBlock)
+logit_bwd_dw_kernel(const float* __restrict__ dz, int64_t ld_dz, const int64_t* __restrict__ seg_ptr,
+                    const int64_t* __restrict__ src, int64_t m, int h, int mean,
+                    const float* __restrict__ w_l, int64_t ld_wl, const float* __restrict__ w_r, int64_t ld_wr,
+                    int n, float* __restrict__ dh, int64_t ld_dh, const float* __restrict__ row_loss,
+                    float* __restrict__ loss, int seed_blocks, LogitDwArgs d) {
+  static_assert(kLogitBlock == kSkinnyThreads, "skinny_dweight_body runs on 256 threads");
+  if (static_cast<int>(blockIdx.x) >= seed_blocks) {      // (uniform over the workgroup)
+    const int id = blockIdx.x - seed_blocks;
+    skinny_dweight_body(id % d.gx, id / d.gx % d.gy, id / (d.gx * d.gy), dz, ld_dz, d.p0, d.p1, d.slices, m, d.m_dev, n,
+                        d.m_chunk, nullptr);
+    return;
+  }
+  logit_bwd_body<NC, FULL>(dz, ld_dz, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, dh, ld_dh, row_loss, loss);
+}
+
 inline bool vec16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int check_common(const char* who, sage_i64 m, int h, int n, int reduce, const float* w_l, sage_i64 ld_wl,
@@ -493,7 +531,13 @@ int allow_lds(K kernel, size_t bytes, const char* who) {
   for (const auto& d : done) {
     if (d == key) return SAGE_OK;
   }
-  SAGE_REQUIRE(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess,
+  // (static LDS of the kernel — the weight-gradient workgroups' 2 KB stage — counts against the same 160 KB)
+  hipFuncAttributes attr;
+  SAGE_REQUIRE(hipFuncGetAttributes(&attr, key.first) == hipSuccess, SAGE_ELAUNCH, "%s: cannot query the kernel", who);
+  const int max_dyn = 160 * 1024 - static_cast<int>(attr.sharedSizeBytes);
+  SAGE_REQUIRE(static_cast<long long>(bytes) <= max_dyn, SAGE_ELIMIT, "%s: %zu bytes of weights beside %zu bytes of static LDS",
+               who, bytes, static_cast<size_t>(attr.sharedSizeBytes));
+  SAGE_REQUIRE(hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn) == hipSuccess,
                SAGE_ELAUNCH, "%s: cannot raise the dynamic LDS limit", who);
   done.push_back(key);
   return SAGE_OK;
@@ -573,26 +617,35 @@ extern "C" int sage_logit_layer_infer(const float* h_rows, sage_i64 ld_h, int pr
                           pred, static_cast<hipStream_t>(stream_));
 }
 
-extern "C" int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
-                                    sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
-                                    const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,
-                                    const float* row_loss, float* loss, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+namespace {
+int launch_logit_bwd(const char* who, const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
+                     sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr,
+                     int n, float* dh, sage_i64 ld_dh, const float* row_loss, float* loss, const LogitDwArgs* dw,
+                     hipStream_t stream) {
   size_t lds = 0;
-  const int rc = check_common("sage_logit_layer_bwd", m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
+  const int rc = check_common(who, m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
   if (rc != SAGE_OK) return rc;
   SAGE_REQUIRE(dz && seg_ptr && src && dh && ld_dz >= n && ld_dh >= h, SAGE_EINVAL,
-               "sage_logit_layer_bwd: NULL pointer argument or row stride below the width");
-  SAGE_REQUIRE((loss == nullptr) == (row_loss == nullptr), SAGE_EINVAL,
-               "sage_logit_layer_bwd: pass row_loss and loss together (or neither)");
-  const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
+               "%s: NULL pointer argument or row stride below the width", who);
+  SAGE_REQUIRE((loss == nullptr) == (row_loss == nullptr), SAGE_EINVAL, "%s: pass row_loss and loss together (or neither)",
+               who);
+  const unsigned seed_blocks = static_cast<unsigned>(cdiv(m, kLogitWaves));
   const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
 #define SAGE_LOGIT_BWD(NC, FULL)                                                                                \
   do {                                                                                                      \
-    const int rc2 = allow_lds(logit_bwd_kernel<NC, FULL>, lds, "sage_logit_layer_bwd");                     \
-    if (rc2 != SAGE_OK) return rc2;                                                                         \
-    logit_bwd_kernel<NC, FULL><<<grid, kLogitBlock, lds, stream>>>(dz, ld_dz, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, \
-                                                                   ld_wr, n, dh, ld_dh, row_loss, loss);    \
+    if (dw == nullptr) {                                                                                    \
+      const int rc2 = allow_lds(logit_bwd_kernel<NC, FULL>, lds, who);                                      \
+      if (rc2 != SAGE_OK) return rc2;                                                                       \
+      logit_bwd_kernel<NC, FULL><<<seed_blocks, kLogitBlock, lds, stream>>>(                                \
+          dz, ld_dz, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, dh, ld_dh, row_loss, loss);       \
+    } else {                                                                                                \
+      const int rc2 = allow_lds(logit_bwd_dw_kernel<NC, FULL>, lds, who);                                   \
+      if (rc2 != SAGE_OK) return rc2;                                                                       \
+      const unsigned grid = seed_blocks + static_cast<unsigned>(dw->gx * dw->gy * 2 * dw->slices);          \
+      logit_bwd_dw_kernel<NC, FULL><<<grid, kLogitBlock, lds, stream>>>(                                    \
+          dz, ld_dz, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, dh, ld_dh, row_loss, loss,        \
+          static_cast<int>(seed_blocks), *dw);                                                              \
+    }                                                                                                       \
   } while (0)
   const int nc = (h + kWave - 1) / kWave;
   if (h == 256) SAGE_LOGIT_BWD(4, true);
@@ -602,4 +655,46 @@ extern "C" int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_
 #undef SAGE_LOGIT_BWD
   SAGE_CHECK_LAUNCH("logit_bwd_kernel");
   return SAGE_OK;
+}
+}  // namespace
+
+extern "C" int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
+                                    sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                                    const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,
+                                    const float* row_loss, float* loss, void* stream_) {
+  return launch_logit_bwd("sage_logit_layer_bwd", dz, ld_dz, seg_ptr, src, m, h, reduce, w_l, ld_wl, w_r, ld_wr, n, dh,
+                          ld_dh, row_loss, loss, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int sage_logit_layer_bwd_dw(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
+                                       sage_i64 m, const sage_i64* m_dev, int h, int reduce, const float* w_l,
+                                       sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n, float* dh,
+                                       sage_i64 ld_dh, const float* row_loss, float* loss, const float* agg,
+                                       sage_i64 ld_agg, float* dw_l, sage_i64 ld_dwl, const float* h_root,
+                                       sage_i64 ld_h_root, float* dw_r, sage_i64 ld_dwr, void* stream_) {
+  SAGE_REQUIRE(agg && dw_l && h_root && dw_r && ld_agg >= h && ld_dwl >= h && ld_h_root >= h && ld_dwr >= h, SAGE_EINVAL,
+               "sage_logit_layer_bwd_dw: NULL weight-gradient operand or row stride below the width");
+  SAGE_REQUIRE(m > 0 && m < (1ll << 31), SAGE_ELIMIT, "sage_logit_layer_bwd_dw: m out of range");
+  if (static_cast<size_t>(n) * 2 * h * sizeof(float) + 4096 > 160 * 1024) {
+    // no room for the weight-gradient workgroups' stage beside the weights: two launches
+    const int rc = sage_linear_dweight2(dz, ld_dz, agg, ld_agg, nullptr, h, dw_l, ld_dwl, h_root, ld_h_root, nullptr, h,
+                                        dw_r, ld_dwr, m, m_dev, n, stream_);
+    if (rc != SAGE_OK) return rc;
+    return sage_logit_layer_bwd(dz, ld_dz, seg_ptr, src, m, h, reduce, w_l, ld_wl, w_r, ld_wr, n, dh, ld_dh, row_loss,
+                                loss, stream_);
+  }
+  // the grid of sage_linear_dweight2's skinny pair: >= 32 rows of m per block, <= 16 slices
+  LogitDwArgs d = {};
+  d.p0 = {agg, ld_agg, nullptr, h, dw_l, ld_dwl};
+  d.p1 = {h_root, ld_h_root, nullptr, h, dw_r, ld_dwr};
+  int64_t sp = cdiv(m, 32);
+  if (sp > 16) sp = 16;
+  if (sp < 1) sp = 1;
+  d.m_chunk = static_cast<int>(cdiv(m, sp));
+  d.slices = static_cast<int>(cdiv(m, d.m_chunk));
+  d.gx = static_cast<int>(cdiv(h, kSkinnyThreads));
+  d.gy = static_cast<int>(cdiv(n, kDwRows));
+  d.m_dev = m_dev;
+  return launch_logit_bwd("sage_logit_layer_bwd_dw", dz, ld_dz, seg_ptr, src, m, h, reduce, w_l, ld_wl, w_r, ld_wr, n, dh,
+                          ld_dh, row_loss, loss, &d, static_cast<hipStream_t>(stream_));
 }

@@ -188,6 +188,8 @@ class SageTrainEngine:
                             and not self.multilabel
                             and self.root and self.reduce in ('mean', 'sum') and len(model.layers) >= 2
                             and ops.logit_layer_supported(last_w.size(1), last_w.size(0)))
+        # ... with the layer's weight gradients in the backward's launch (SAGE_NO_FUSED_LOGIT_DW=1: a launch of their own)
+        self.fused_logit_dw = self.fused_logit and not os.environ.get('SAGE_NO_FUSED_LOGIT_DW')
         # ... and reads the hidden layer's PRE-activation rows (SAGE_NO_PRENORM=1: normalise pass kept)
         self.prenorm = self.fused_logit and not os.environ.get('SAGE_NO_PRENORM')
         self.features, self.labels = features, labels
@@ -771,6 +773,13 @@ class SageTrainEngine:
             x_in = self.features if i == 0 else act[i - 1]['h']
             rows = self._node_map(slot, v) if i == 0 else None
             agg_i = self._agg0(slot, v) if i == 0 else a['agg']
+            if fused and i == L - 1 and self.fused_logit_dw:
+                # the class-logit layer's backward and its two (skinny) weight gradients in one
+                # launch: the gradients' workgroups run on the CUs the 128 seed workgroups leave idle
+                lib.logit_layer_bwd_dw(a['dz'], buf.seg_ptr, buf.src, self.B, self.reduce, layer.lin_l.weight,
+                                       layer.lin_r.weight, act[i - 1]['dh'], agg_i, self.gviews[layer.lin_l.weight],
+                                       x_in, self.gviews[layer.lin_r.weight], self.row_loss, self.loss, m_dev=t_dev)
+                continue
             with self._leaf(t_cap):
                 if self.root:
                     lib.linear_dweight2(a['dz'], agg_i, self.gviews[layer.lin_l.weight], x_in,

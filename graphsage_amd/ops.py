@@ -913,6 +913,35 @@ def logit_layer_bwd(dz, seg_ptr, src, m, reduce, w_l, w_r, dh, row_loss=None, lo
     _lib.check(rc, "sage_logit_layer_bwd")
 
 
+def logit_layer_bwd_dw(dz, seg_ptr, src, m, reduce, w_l, w_r, dh, agg, dw_l, h_root, dw_r, row_loss=None, loss=None,
+                       m_dev=None):
+    """logit_layer_bwd plus the layer's weight gradients in the same launch:
+    dw_l += dz[:m]^T @ agg[:m], dw_r += dz[:m]^T @ h_root[:m] (rows limited by m_dev if given)."""
+    lib = _lib.load()
+    dp, ld_dz = _mat(dz, "dz")
+    wlp, ld_wl = _mat(w_l, "w_l")
+    wrp, ld_wr = _mat(w_r, "w_r")
+    n, h = w_l.shape
+    m = int(m)
+    hp, ld_dh = _mat(dh, "dh")
+    ap, ld_agg = _mat(agg, "agg")
+    rp, ld_hr = _mat(h_root, "h_root")
+    glp, ld_gl = _mat(dw_l, "dw_l")
+    grp, ld_gr = _mat(dw_r, "dw_r")
+    if tuple(w_r.shape) != (n, h) or dz.size(0) < m or dz.size(1) != n or dh.size(1) != h or dh.size(0) < m \
+            or seg_ptr.numel() < m + 1 or (row_loss is None) != (loss is None) \
+            or (row_loss is not None and row_loss.numel() < m) \
+            or agg.size(0) < m or agg.size(1) != h or h_root.size(0) < m or h_root.size(1) != h \
+            or tuple(dw_l.shape) != (n, h) or tuple(dw_r.shape) != (n, h):
+        raise RuntimeError("logit_layer_bwd_dw: bad buffers")
+    rc = lib.sage_logit_layer_bwd_dw(dp, ld_dz, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), m,
+                                     _count(m_dev, "m_dev"), h, REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n, hp, ld_dh,
+                                     _vec(row_loss, torch.float32, "row_loss", allow_none=True),
+                                     _p(loss, torch.float32, "loss", allow_none=True), ap, ld_agg, glp, ld_gl,
+                                     rp, ld_hr, grp, ld_gr, _stream())
+    _lib.check(rc, "sage_logit_layer_bwd_dw")
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8,
               weight_decay=0.0, grad_scale=1.0, step_out=None, zero_grad=False):
     """torch.optim.Adam step on flat fp32 buffers.  The step count is read from step_dev

@@ -548,6 +548,17 @@ int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_pt
                          sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
                          const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,
                          const float* row_loss, float* loss, void* stream);
+/* sage_logit_layer_bwd with the layer's two weight gradients in the same launch (what
+ * loss.backward() leaves in lin_l.weight.grad / lin_r.weight.grad of the last SAGE layer,
+ * layers/sage.py:129-131):  dw_l[n, h] += dz[0:m]^T . agg[0:m],  dw_r[n, h] += dz[0:m]^T . h_root[0:m]
+ * (= sage_linear_dweight2 for n <= 64; rows limited by *m_dev if given) — they run in workgroups
+ * of their own behind the seeds' workgroups, which leave half of the CUs idle. */
+int sage_logit_layer_bwd_dw(const float* dz, sage_i64 ld_dz, const sage_i64* seg_ptr, const sage_i64* src,
+                            sage_i64 m, const sage_i64* m_dev, int h, int reduce, const float* w_l,
+                            sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n, float* dh,
+                            sage_i64 ld_dh, const float* row_loss, float* loss, const float* agg,
+                            sage_i64 ld_agg, float* dw_l, sage_i64 ld_dwl, const float* h_root,
+                            sage_i64 ld_h_root, float* dw_r, sage_i64 ld_dwr, void* stream);
 /* The same layer forward-only, for the inference pass (GraphSAGE.inference,
  * models/graphsage.py:51-68, and the `y_hat.argmax(dim=-1)` of the runners' test(),
  * fig2a/runners/graphsage_runners.py:57-66 / trainers/node_level_graphsage_trainers.py:56):

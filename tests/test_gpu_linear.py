@@ -679,6 +679,29 @@ def test_logit_layer_fused_matches_separate_kernels(dev, reduce, h, n):
     want.backward()
     torch.testing.assert_close(loss.double().view(()), want.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(dh.double(), hr.grad, rtol=1e-4, atol=1e-6)
+    # sage_logit_layer_bwd_dw: the same backward with the two weight gradients in its launch —
+    # against the plain call + linear_dweight2 and against torch.autograd's weight gradients; the
+    # gradients are ADDED to what the buffers hold; rows limited by a device-side count
+    wl64 = w_l.double().clone().requires_grad_(True)
+    wr64 = w_r.double().clone().requires_grad_(True)
+    F.cross_entropy(F.normalize(a.detach() @ wl64.t() + hrows[:m].double() @ wr64.t(), p=2.0, dim=-1),
+                    labels[node]).backward()
+    for live in (m, m - 9):
+        gbuf = torch.randn(2 * n, ldh, generator=g, device=dev)
+        g0 = gbuf.clone()
+        dh3, loss3 = torch.zeros_like(dh), torch.zeros_like(loss)
+        m_dev = None if live == m else torch.tensor([live], device=dev)
+        ops.logit_layer_bwd_dw(dz, seg_ptr, src, m, reduce, w_l, w_r, dh3, agg, gbuf[:n, :h], hrows, gbuf[n:, :h],
+                               row_loss, loss3, m_dev=m_dev)
+        torch.testing.assert_close(dh3, dh, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(loss3, loss, rtol=0, atol=0)
+        ref = g0.clone()
+        ops.linear_dweight2(dz, agg, ref[:n, :h], hrows, ref[n:, :h], m=m, m_dev=m_dev)
+        torch.testing.assert_close(gbuf, ref, rtol=1e-5, atol=1e-6)
+        assert torch.equal(gbuf[:, h:], g0[:, h:])                       # the padding columns are not touched
+        if live == m:
+            torch.testing.assert_close((gbuf - g0)[:n, :h].double(), wl64.grad, rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close((gbuf - g0)[n:, :h].double(), wr64.grad, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("reduce,h,n", [("mean", 256, 41), ("sum", 64, 7), ("mean", 512, 40), ("mean", 36, 5),
