@@ -67,6 +67,9 @@ SIGNATURES = {
     "sage_l2norm_relu_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int64, _P, c_int,
                                      _P, c_int64, c_int, _P]),
     "sage_l2norm_relu_bwd_z": (c_int, [_P, c_int64, _P, c_int64, c_int, c_int64, _P, c_int, _P, c_int64, c_int, _P]),
+    "sage_l2norm_relu_bwd_z_dw": (c_int, [_P, c_int64, _P, c_int64, c_int, c_int64, _P, c_int, _P, c_int64, c_int,
+                                          _P, c_int64, c_int64, _P, c_int, c_int, _P, c_int64, _P, c_int64,
+                                          _P, c_int64, _P, c_int64, _P, _P, _P]),
     "sage_relu_bwd": (c_int, [_P, c_int64, _P, c_int64, c_int64, _P, c_int, _P, c_int64, c_int, _P]),
     "sage_pool_linear_fwd": (c_int, [_P, c_int64, _P, c_int, _P, c_int64, _P, c_int64, _P, c_int, _P, c_int64,
                                      _P, c_int64, _P]),
@@ -83,6 +86,9 @@ SIGNATURES = {
                                       c_int64, _P, _P, _P, c_int, _P]),
     "sage_logit_layer_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
                                      _P, _P, c_float, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64, _P]),
+    "sage_logit_layer_fwd_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
+                                         _P, _P, c_float, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64,
+                                         _P, c_int64, _P]),
     "sage_logit_layer_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
                                      _P, c_int64, _P, _P, _P]),
     "sage_logit_layer_bwd_dw": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, c_int, _P, c_int64, _P, c_int64, c_int,

@@ -137,7 +137,9 @@ struct WeightStage {
 // in registers on its way in (one DPP reduction per row, 16 rows at a time), so the previous
 // layer's normalise pass — 54 MB and a launch — is not run at all; the seeds' own activations
 // are written to h_root for the root term's weight gradient.
-template <int NV, bool FULL, bool PRE>      // FULL: h == 256 NV, no lane is ever out of the row
+// BWD: the seed's backward in the same wave, behind its forward (dz never leaves the lanes, the
+// weights are staged once): dh[src[e]] += (dz . W_l) (/ deg), dh[t] += dz . W_r as in logit_bwd_body.
+template <int NV, bool FULL, bool PRE, bool BWD = false>      // FULL: h == 256 NV, no lane is ever out of the row
 __global__ void __launch_bounds__(kLogitBlock)
 logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
                  const int64_t* __restrict__ src, int64_t m, int h, int mean,
@@ -146,7 +148,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
                  float grad_scale, float* __restrict__ agg, int64_t ld_agg, float* __restrict__ y, int64_t ld_y,
                  float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
                  float* __restrict__ row_loss, float* __restrict__ h_root, int64_t ld_h_root,
-                 int64_t* __restrict__ pred) {
+                 int64_t* __restrict__ pred, float* __restrict__ dh, int64_t ld_dh) {
   // Forward-only callers (sage_logit_layer_infer) pass labels = agg = dz = row_loss = NULL and
   // take y and / or pred (the arg-max class of each seed row); every one of these tests is
   // wave-uniform.
@@ -369,11 +371,63 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
     if (inv_norm != nullptr) inv_norm[t] = inv;
     row_loss[t] = (lab >= 0 && lab < n) ? lse - at_label : 0.f;
   }
+  const float dzv = has ? (g - yv * dot) * inv : 0.f;
   if (has) {
     if (y != nullptr) y[t * ld_y + lane] = yv;
-    dz[t * ld_dz + lane] = (g - yv * dot) * inv;
+    dz[t * ld_dz + lane] = dzv;
   }
   LOGIT_STAMP(0, 6);
+  if constexpr (BWD) {
+    // (lane l owns columns l + 64 k here: every atomic wave-instruction adds 256 contiguous bytes)
+    constexpr int NC = 4 * NV;
+    float da[NC], dr[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) da[k] = dr[k] = 0.f;
+    for (int c0 = 0; c0 < n; c0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j < n ? c0 + j : n - 1;
+        float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dzv), c));   // c is wave-uniform
+        if (c0 + j >= n) d = 0.f;
+        const float* wl = wlds + static_cast<int64_t>(c) * 2 * h;
+        const float* wr = wl + h;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          if (FULL || lane + kWave * k < h) {
+            da[k] += d * wl[lane + kWave * k];
+            dr[k] += d * wr[lane + kWave * k];
+          }
+        }
+      }
+    }
+    float* rootp = dh + t * ld_dh;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      if (FULL || lane + kWave * k < h) atomicAdd(rootp + lane + kWave * k, dr[k]);
+    }
+    if (len <= 0) return;
+    if (mean) {
+      const float cnt = static_cast<float>(len);
+#pragma unroll
+      for (int k = 0; k < NC; ++k) da[k] /= cnt;
+    }
+    for (int64_t base = 0; base < len; base += kWave) {
+      const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
+      int64_t my = my0;
+      if (base > 0) {
+        my = 0;
+        if (lane < chunk) my = src[s0 + base + lane];
+      }
+      for (int r = 0; r < chunk; ++r) {
+        float* rowp = dh + readlane64(my, r) * ld_dh;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          if (FULL || lane + kWave * k < h) atomicAdd(rowp + lane + kWave * k, da[k]);
+        }
+      }
+    }
+    LOGIT_STAMP(0, 7);
+  }
 }
 
 // NC = H / 64 (a lane owns columns lane + 64 k)
@@ -553,24 +607,29 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
                      sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n,
                      const sage_i64* labels, const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
                      float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz, float* row_loss, float* h_root,
-                     sage_i64 ld_h_root, sage_i64* pred, hipStream_t stream) {
+                     sage_i64 ld_h_root, sage_i64* pred, float* dh, sage_i64 ld_dh, hipStream_t stream) {
   size_t lds = 0;
   const int rc = check_common(who, m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
   if (rc != SAGE_OK) return rc;
   const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
   const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
-#define SAGE_LOGIT_FWD_P(NV, FULL, PRE)                                                                         \
+#define SAGE_LOGIT_FWD_P(NV, FULL, PRE, BWD)                                                                    \
   do {                                                                                                      \
-    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE>, lds, who);                                   \
+    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE, BWD>, lds, who);                              \
     if (rc2 != SAGE_OK) return rc2;                                                                         \
-    logit_fwd_kernel<NV, FULL, PRE><<<grid, kLogitBlock, lds, stream>>>(                                    \
+    logit_fwd_kernel<NV, FULL, PRE, BWD><<<grid, kLogitBlock, lds, stream>>>(                               \
         h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, \
-        ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, pred);                                      \
+        ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, pred, dh, ld_dh);                           \
   } while (0)
 #define SAGE_LOGIT_FWD(NV, FULL)                                                                                \
   do {                                                                                                      \
-    if (pre) SAGE_LOGIT_FWD_P(NV, FULL, true);                                                              \
-    else SAGE_LOGIT_FWD_P(NV, FULL, false);                                                                 \
+    if (dh != nullptr) {                                                                                    \
+      if (pre) SAGE_LOGIT_FWD_P(NV, FULL, true, true);                                                      \
+      else SAGE_LOGIT_FWD_P(NV, FULL, false, true);                                                         \
+    } else {                                                                                                \
+      if (pre) SAGE_LOGIT_FWD_P(NV, FULL, true, false);                                                     \
+      else SAGE_LOGIT_FWD_P(NV, FULL, false, false);                                                        \
+    }                                                                                                       \
   } while (0)
   const int nv = (h / 4 + kWave - 1) / kWave;
   const bool full = h == nv * 4 * kWave;
@@ -601,7 +660,27 @@ extern "C" int sage_logit_layer_fwd(const float* h_rows, sage_i64 ld_h, const sa
                "sage_logit_layer_fwd: rows of h_root must be 16-byte aligned and at least h wide, and not alias h_rows");
   return launch_logit_fwd("sage_logit_layer_fwd", h_root != nullptr, h_rows, ld_h, seg_ptr, src, m, h, reduce, w_l, ld_wl, w_r,
                           ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y, inv_norm, dz, ld_dz, row_loss,
-                          h_root, ld_h_root, nullptr, static_cast<hipStream_t>(stream_));
+                          h_root, ld_h_root, nullptr, nullptr, 0, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
+                                        sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                                        const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
+                                        const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
+                                        float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                                        float* row_loss, float* h_root, sage_i64 ld_h_root, float* dh, sage_i64 ld_dh,
+                                        void* stream_) {
+  SAGE_REQUIRE(h_rows && seg_ptr && src && labels && agg && dz && row_loss && dh, SAGE_EINVAL,
+               "sage_logit_layer_fwd_bwd: NULL pointer argument");
+  SAGE_REQUIRE(ld_h >= 4 && ld_h % 4 == 0 && vec16(h_rows) && ld_agg >= h && ld_agg % 4 == 0 && vec16(agg) && ld_dz >= n &&
+                   (y == nullptr || ld_y >= n) && ld_h >= h && ld_dh >= h,
+               SAGE_EINVAL, "sage_logit_layer_fwd_bwd: rows of h / agg must be 16-byte aligned, ld_dz / ld_y >= n, ld_dh >= h");
+  SAGE_REQUIRE(h_root == nullptr || (ld_h_root >= h && ld_h_root % 4 == 0 && vec16(h_root) && h_root != h_rows), SAGE_EINVAL,
+               "sage_logit_layer_fwd_bwd: rows of h_root must be 16-byte aligned and at least h wide, and not alias h_rows");
+  SAGE_REQUIRE(dh != h_rows && dh != agg && dh != h_root, SAGE_EINVAL, "sage_logit_layer_fwd_bwd: dh aliases an input");
+  return launch_logit_fwd("sage_logit_layer_fwd_bwd", h_root != nullptr, h_rows, ld_h, seg_ptr, src, m, h, reduce, w_l, ld_wl,
+                          w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y, inv_norm, dz, ld_dz, row_loss,
+                          h_root, ld_h_root, nullptr, dh, ld_dh, static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int sage_logit_layer_infer(const float* h_rows, sage_i64 ld_h, int pre_activation, const sage_i64* seg_ptr,
@@ -614,7 +693,7 @@ extern "C" int sage_logit_layer_infer(const float* h_rows, sage_i64 ld_h, int pr
                "sage_logit_layer_infer: rows of h must be 16-byte aligned, ld_y >= n");
   return launch_logit_fwd("sage_logit_layer_infer", pre_activation != 0, h_rows, ld_h, seg_ptr, src, m, h, reduce, w_l, ld_wl,
                           w_r, ld_wr, n, nullptr, nullptr, 1.f, nullptr, 0, y, ld_y, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                          pred, static_cast<hipStream_t>(stream_));
+                          pred, nullptr, 0, static_cast<hipStream_t>(stream_));
 }
 
 namespace {

@@ -8,6 +8,7 @@
 //   F.cross_entropy(y_hat, y)             reference experiments/fig2a/runners/graphsage_runners.py:43
 //   torch.optim.Adam(...).step()          reference experiments/fig2a/runners/graphsage_runners.py:45,86
 #include "common.h"
+#include "skinny_dw.h"
 
 namespace sage {
 namespace {
@@ -147,13 +148,13 @@ l2norm_relu_bwd_kernel(float* __restrict__ dh, int64_t ld_dh, const float* __res
 // row, the row of z and of dh held in registers across both reductions (|z|^2, then <y, g>);
 // z is handed back zeroed, like dh, for the producers that add into it.
 template <int NV>      // float4 per lane: n <= 256 NV
-__global__ void __launch_bounds__(kBlock)
-l2norm_relu_bwd_z_kernel(float* __restrict__ dh, int64_t ld_dh, float* __restrict__ z, int64_t ld_z,
-                         int relu_mask, int64_t m, const int64_t* __restrict__ m_dev, int n,
-                         float* __restrict__ dz, int64_t ld_dz, int clear_dh) {
+__device__ __forceinline__ void
+l2norm_relu_bwd_z_body(int64_t block, float* __restrict__ dh, int64_t ld_dh, float* __restrict__ z, int64_t ld_z,
+                       int relu_mask, int64_t m, const int64_t* __restrict__ m_dev, int n,
+                       float* __restrict__ dz, int64_t ld_dz, int clear_dh) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t rows = dev_count(m_dev, m);
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  const int64_t r = block * kWavesPerBlock + threadIdx.x / kWave;
   if (r >= rows) return;
   const int nq = n / 4;
   float4* zr = reinterpret_cast<float4*>(z + r * ld_z);
@@ -199,6 +200,54 @@ l2norm_relu_bwd_z_kernel(float* __restrict__ dh, int64_t ld_dh, float* __restric
       if (clear_dh) gr[q] = zero4;
     }
   }
+}
+template <int NV>
+__global__ void __launch_bounds__(kBlock)
+l2norm_relu_bwd_z_kernel(float* __restrict__ dh, int64_t ld_dh, float* __restrict__ z, int64_t ld_z,
+                         int relu_mask, int64_t m, const int64_t* __restrict__ m_dev, int n,
+                         float* __restrict__ dz, int64_t ld_dz, int clear_dh) {
+  l2norm_relu_bwd_z_body<NV>(blockIdx.x, dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
+}
+
+// The same pass with the NEXT layer's leftovers riding in front of it (the engine's supervised
+// step: the class-logit layer's forward launch has already sent that layer's input gradient into
+// dh, logit.hip): workgroups 0 .. rider-1 form that layer's two weight gradients
+// (skinny_dweight_body: dw_l += dz2^T agg2, dw_r += dz2^T h_root2) and workgroup `rider` the mean
+// of its row losses in a fixed order; the rest is the pass above.  Nothing a rider reads is
+// written by this launch.
+struct NormDwRider {
+  const float* dz2;
+  int64_t ld_dz2;
+  SkinnyDwProblem p0, p1;
+  int slices, m_chunk, gx, gy, n2;
+  int64_t m2;
+  const int64_t* m2_dev;
+  const float* row_loss;
+  float* loss;
+};
+template <int NV>
+__global__ void __launch_bounds__(kBlock)
+l2norm_relu_bwd_z_dw_kernel(float* __restrict__ dh, int64_t ld_dh, float* __restrict__ z, int64_t ld_z,
+                            int relu_mask, int64_t m, const int64_t* __restrict__ m_dev, int n,
+                            float* __restrict__ dz, int64_t ld_dz, int clear_dh, int rider, NormDwRider d) {
+  static_assert(kBlock == kSkinnyThreads, "skinny_dweight_body runs on 256 threads");
+  const int b = blockIdx.x;
+  if (b < rider) {      // (uniform over the workgroup)
+    skinny_dweight_body(b % d.gx, b / d.gx % d.gy, b / (d.gx * d.gy), d.dz2, d.ld_dz2, d.p0, d.p1, d.slices, d.m2,
+                        d.m2_dev, d.n2, d.m_chunk, nullptr);
+    return;
+  }
+  if (b == rider) {
+    if (d.loss != nullptr && threadIdx.x < kWave) {
+      // loss = mean(row_loss[0 : m2]): lane l adds rows l, l + 64, ... in order, then the butterfly
+      float sl = 0.f;
+      for (int64_t i = threadIdx.x; i < d.m2; i += kWave) sl += d.row_loss[i];
+      sl = wave_sum(sl);
+      if (threadIdx.x == 0) d.loss[0] = sl / static_cast<float>(d.m2);
+    }
+    return;
+  }
+  l2norm_relu_bwd_z_body<NV>(b - rider - 1, dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
 }
 
 // One workgroup of 16 waves walks all rows; per-wave partial losses are combined in wave
@@ -649,6 +698,57 @@ extern "C" int sage_l2norm_relu_bwd_z(float* dh, sage_i64 ld_dh, float* z, sage_
     l2norm_relu_bwd_z_kernel<4><<<grid, kBlock, 0, stream>>>(dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh);
   }
   SAGE_CHECK_LAUNCH("l2norm_relu_bwd_z_kernel");
+  return SAGE_OK;
+}
+
+extern "C" int sage_l2norm_relu_bwd_z_dw(float* dh, sage_i64 ld_dh, float* z, sage_i64 ld_z, int relu_mask, sage_i64 m,
+                                         const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz, int clear_dh,
+                                         const float* dz2, sage_i64 ld_dz2, sage_i64 m2, const sage_i64* m2_dev, int n2,
+                                         int h2, const float* agg2, sage_i64 ld_agg2, float* dw_l, sage_i64 ld_dwl,
+                                         const float* h_root2, sage_i64 ld_h_root2, float* dw_r, sage_i64 ld_dwr,
+                                         const float* row_loss, float* loss, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(m > 0 && n > 0 && ld_dh >= n && ld_z >= n && ld_dz >= n, SAGE_EINVAL, "sage_l2norm_relu_bwd_z_dw: bad shape");
+  SAGE_REQUIRE(dh && z && dz && dz != z && dh != z, SAGE_EINVAL,
+               "sage_l2norm_relu_bwd_z_dw: NULL pointer argument or dz / dh aliasing z");
+  SAGE_REQUIRE(n % 4 == 0 && n <= 1024 && ld_dh % 4 == 0 && ld_z % 4 == 0 && ld_dz % 4 == 0 && vec16(dh) && vec16(z) &&
+                   vec16(dz),
+               SAGE_ELIMIT, "sage_l2norm_relu_bwd_z_dw: needs 16-byte aligned rows of at most 1024 floats, a multiple of 4");
+  SAGE_REQUIRE(dz2 && agg2 && dw_l && h_root2 && dw_r && m2 > 0 && m2 < (1ll << 31) && n2 > 0 && n2 <= 64 && h2 > 0 &&
+                   ld_dz2 >= n2 && ld_agg2 >= h2 && ld_dwl >= h2 && ld_h_root2 >= h2 && ld_dwr >= h2,
+               SAGE_EINVAL, "sage_l2norm_relu_bwd_z_dw: bad weight-gradient operands (n2 <= 64)");
+  SAGE_REQUIRE((loss == nullptr) == (row_loss == nullptr), SAGE_EINVAL,
+               "sage_l2norm_relu_bwd_z_dw: pass row_loss and loss together (or neither)");
+  SAGE_REQUIRE(dz2 != dz && dz2 != dh && agg2 != dz && h_root2 != dz, SAGE_EINVAL,
+               "sage_l2norm_relu_bwd_z_dw: the weight-gradient operands must not be written by this pass");
+  // the grid of sage_linear_dweight2's skinny pair: >= 32 rows of m2 per block, <= 16 slices
+  NormDwRider d = {};
+  d.dz2 = dz2;
+  d.ld_dz2 = ld_dz2;
+  d.p0 = {agg2, ld_agg2, nullptr, h2, dw_l, ld_dwl};
+  d.p1 = {h_root2, ld_h_root2, nullptr, h2, dw_r, ld_dwr};
+  int64_t sp = cdiv(m2, 32);
+  if (sp > 16) sp = 16;
+  if (sp < 1) sp = 1;
+  d.m_chunk = static_cast<int>(cdiv(m2, sp));
+  d.slices = static_cast<int>(cdiv(m2, d.m_chunk));
+  d.gx = static_cast<int>(cdiv(h2, kSkinnyThreads));
+  d.gy = static_cast<int>(cdiv(n2, kDwRows));
+  d.n2 = n2;
+  d.m2 = m2;
+  d.m2_dev = m2_dev;
+  d.row_loss = row_loss;
+  d.loss = loss;
+  const int rider = d.gx * d.gy * 2 * d.slices;
+  const unsigned grid = static_cast<unsigned>(cdiv(m, kWavesPerBlock)) + rider + 1;
+  if (n <= 256) {
+    l2norm_relu_bwd_z_dw_kernel<1><<<grid, kBlock, 0, stream>>>(dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh, rider, d);
+  } else if (n <= 512) {
+    l2norm_relu_bwd_z_dw_kernel<2><<<grid, kBlock, 0, stream>>>(dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh, rider, d);
+  } else {
+    l2norm_relu_bwd_z_dw_kernel<4><<<grid, kBlock, 0, stream>>>(dh, ld_dh, z, ld_z, relu_mask, m, m_dev, n, dz, ld_dz, clear_dh, rider, d);
+  }
+  SAGE_CHECK_LAUNCH("l2norm_relu_bwd_z_dw_kernel");
   return SAGE_OK;
 }
 

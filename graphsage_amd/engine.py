@@ -192,6 +192,11 @@ class SageTrainEngine:
         self.fused_logit_dw = self.fused_logit and not os.environ.get('SAGE_NO_FUSED_LOGIT_DW')
         # ... and reads the hidden layer's PRE-activation rows (SAGE_NO_PRENORM=1: normalise pass kept)
         self.prenorm = self.fused_logit and not os.environ.get('SAGE_NO_PRENORM')
+        # ... and, with those, needs no backward launch of its own at all: every seed's wave runs its
+        # backward behind its forward (sage_logit_layer_fwd_bwd), the layer's weight gradients and the
+        # loss mean ride in front of the hidden layer's normalise-backward pass
+        # (sage_l2norm_relu_bwd_z_dw).  SAGE_NO_LOGIT_FWDBWD=1: forward and backward launches apart.
+        self.logit_fwdbwd = self.prenorm and self.fused_logit_dw and not os.environ.get('SAGE_NO_LOGIT_FWDBWD')
         self.features, self.labels = features, labels
         self.B = int(batch_size)
         self.L = len(model.layers)
@@ -709,7 +714,8 @@ class SageTrainEngine:
             # backward works from z as well (sage_l2norm_relu_bwd_z) and hands it back zeroed
             lib.logit_layer_fwd(prev['z'] if self.prenorm else prev['h'], buf.seg_ptr, buf.src, B, self.reduce,
                                 layer.lin_l.weight, layer.lin_r.weight, self.labels, buf.node, last['agg'], last['y'],
-                                last['inv'], last['dz'], self.row_loss, h_root=prev['h'] if self.prenorm else None)
+                                last['inv'], last['dz'], self.row_loss, h_root=prev['h'] if self.prenorm else None,
+                                dh=prev['dh'] if self.logit_fwdbwd else None)
             return
         if not self.unsup:
             self._forward_layers(slot, 0, skip_gather0)
@@ -765,7 +771,13 @@ class SageTrainEngine:
             a, layer = act[i], self.model.layers[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
             if i < L - 1:   # g = gradient w.r.t. relu(normalize(z)), left in dh by layer i+1
-                if fused and self.prenorm and i == L - 2:
+                if fused and self.logit_fwdbwd and i == L - 2:
+                    nxt, lay2 = act[i + 1], self.model.layers[i + 1]
+                    lib.l2norm_relu_bwd_z_dw(a['dh'], a['z'], True, t_cap, t_dev, a['dz'], True,
+                                             nxt['dz'], self.B, self.n_dev[slot][nxt['hop']], nxt['agg'],
+                                             self.gviews[lay2.lin_l.weight], a['h'], self.gviews[lay2.lin_r.weight],
+                                             self.row_loss, self.loss)
+                elif fused and self.prenorm and i == L - 2:
                     lib.l2norm_relu_bwd_z(a['dh'], a['z'], True, m=t_cap, m_dev=t_dev, dz=a['dz'], clear_dh=True)
                 else:
                     lib.l2norm_relu_bwd(a['dh'], a['y'], a['inv'], True, m=t_cap, m_dev=t_dev, dz=a['dz'],
@@ -773,6 +785,8 @@ class SageTrainEngine:
             x_in = self.features if i == 0 else act[i - 1]['h']
             rows = self._node_map(slot, v) if i == 0 else None
             agg_i = self._agg0(slot, v) if i == 0 else a['agg']
+            if fused and i == L - 1 and self.logit_fwdbwd:
+                continue      # input gradient: done by the forward launch; weight gradients: ride on layer i-1's pass
             if fused and i == L - 1 and self.fused_logit_dw:
                 # the class-logit layer's backward and its two (skinny) weight gradients in one
                 # launch: the gradients' workgroups run on the CUs the 128 seed workgroups leave idle

@@ -731,6 +731,36 @@ def l2norm_relu_bwd_z(dh, z, relu, m=None, m_dev=None, dz=None, clear_dh=False):
     return dz
 
 
+def l2norm_relu_bwd_z_dw(dh, z, relu, m, m_dev, dz, clear_dh, dz2, m2, m2_dev, agg2, dw_l, h_root2, dw_r,
+                         row_loss=None, loss=None):
+    """l2norm_relu_bwd_z with the weight gradients of the class-logit layer above riding along:
+    dw_l += dz2[:m2]^T @ agg2[:m2], dw_r += dz2[:m2]^T @ h_root2[:m2], loss = mean(row_loss[:m2])."""
+    lib = _lib.load()
+    dp, ld_dh = _mat(dh, "dh")
+    zp, ld_z = _mat(z, "z")
+    m, m2 = int(m), int(m2)
+    n = z.size(1)
+    op, ld_dz = _mat(dz, "dz")
+    d2p, ld_dz2 = _mat(dz2, "dz2")
+    ap, ld_agg = _mat(agg2, "agg2")
+    rp, ld_hr = _mat(h_root2, "h_root2")
+    glp, ld_gl = _mat(dw_l, "dw_l")
+    grp, ld_gr = _mat(dw_r, "dw_r")
+    n2, h2 = dw_l.shape
+    if dh.size(0) < m or dh.size(1) != n or dz.size(0) < m or dz.size(1) != n or z.size(0) < m \
+            or dz2.size(0) < m2 or dz2.size(1) != n2 or agg2.size(0) < m2 or agg2.size(1) != h2 \
+            or h_root2.size(0) < m2 or h_root2.size(1) != h2 or tuple(dw_r.shape) != (n2, h2) \
+            or (row_loss is None) != (loss is None) or (row_loss is not None and row_loss.numel() < m2):
+        raise RuntimeError("l2norm_relu_bwd_z_dw: bad buffers")
+    rc = lib.sage_l2norm_relu_bwd_z_dw(dp, ld_dh, zp, ld_z, 1 if relu else 0, m, _count(m_dev, "m_dev"), n, op, ld_dz,
+                                       1 if clear_dh else 0, d2p, ld_dz2, m2, _count(m2_dev, "m2_dev"), n2, h2,
+                                       ap, ld_agg, glp, ld_gl, rp, ld_hr, grp, ld_gr,
+                                       _vec(row_loss, torch.float32, "row_loss", allow_none=True),
+                                       _p(loss, torch.float32, "loss", allow_none=True), _stream())
+    _lib.check(rc, "sage_l2norm_relu_bwd_z_dw")
+    return dz
+
+
 def softmax_xent(logits, labels, label_rows=None, m=None, grad_scale=1.0, loss=None,
                  dlogits=None, want_grad=True, checked=False, row_loss=None):
     """Mean cross-entropy + gradient (reference fig2a/runners/graphsage_runners.py:43).
@@ -835,12 +865,14 @@ def logit_layer_supported(h, n):
 
 
 def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_rows, agg, y, inv_norm, dz,
-                    row_loss, grad_scale=1.0, h_root=None):
+                    row_loss, grad_scale=1.0, h_root=None, dh=None):
     """The last SAGE layer on the m seed rows + normalise + cross entropy + d loss / d z in one
     launch (reference layers/sage.py:99-134 + fig2a/runners/graphsage_runners.py:41-43); all
     buffers are the caller's (static-shape engine).  agg [m, h] is kept for the weight gradients.
     h_root [>= m, h]: h_rows holds the previous layer's PRE-activation rows; the kernel takes
-    every row through relu(normalize(.)) itself and stores the seeds' activations there."""
+    every row through relu(normalize(.)) itself and stores the seeds' activations there.
+    dh [rows of h_rows, h]: the layer's input gradient is added to it in the same launch
+    (sage_logit_layer_fwd_bwd = this + logit_layer_bwd without the loss mean)."""
     lib = _lib.load()
     hp, ld_h = _mat(h_rows, "h_rows")
     wlp, ld_wl = _mat(w_l, "w_l")
@@ -859,12 +891,18 @@ def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_row
     rp, ld_root = (None, 0) if h_root is None else _mat(h_root, "h_root")
     if h_root is not None and (h_root.size(0) < m or h_root.size(1) != h):
         raise RuntimeError("logit_layer_fwd: bad h_root buffer")
-    rc = lib.sage_logit_layer_fwd(hp, ld_h, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), m, h,
-                                  REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n, _vec(labels, torch.int64, "labels"),
-                                  _vec(label_rows, torch.int64, "label_rows", allow_none=True), float(grad_scale),
-                                  ap, ld_agg, yp, ld_y, _vec(inv_norm, torch.float32, "inv_norm", allow_none=True),
-                                  dp, ld_dz, _vec(row_loss, torch.float32, "row_loss"), rp, ld_root, _stream())
-    _lib.check(rc, "sage_logit_layer_fwd")
+    args = (hp, ld_h, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), m, h,
+            REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n, _vec(labels, torch.int64, "labels"),
+            _vec(label_rows, torch.int64, "label_rows", allow_none=True), float(grad_scale),
+            ap, ld_agg, yp, ld_y, _vec(inv_norm, torch.float32, "inv_norm", allow_none=True),
+            dp, ld_dz, _vec(row_loss, torch.float32, "row_loss"), rp, ld_root)
+    if dh is None:
+        _lib.check(lib.sage_logit_layer_fwd(*args, _stream()), "sage_logit_layer_fwd")
+        return
+    gp, ld_dh = _mat(dh, "dh")
+    if dh.size(1) != h or dh.size(0) < h_rows.size(0):
+        raise RuntimeError("logit_layer_fwd: dh must cover the rows of h_rows")
+    _lib.check(lib.sage_logit_layer_fwd_bwd(*args, gp, ld_dh, _stream()), "sage_logit_layer_fwd_bwd")
 
 
 def logit_layer_infer(h_rows, seg_ptr, src, m, reduce, w_l, w_r, y=None, pred=None, pre_activation=False):

@@ -420,6 +420,21 @@ int sage_l2norm_relu_bwd(float* dh, sage_i64 ld_dh, const float* y, sage_i64 ld_
 int sage_l2norm_relu_bwd_z(float* dh, sage_i64 ld_dh, float* z, sage_i64 ld_z, int relu_mask,
                            sage_i64 m, const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz,
                            int clear_dh, void* stream);
+/* sage_l2norm_relu_bwd_z of the hidden layer with the leftovers of the class-logit layer above
+ * it in the same launch (the supervised step after sage_logit_layer_fwd_bwd; what
+ * loss.backward() leaves in the last SAGE layer's lin_l.weight.grad / lin_r.weight.grad,
+ * layers/sage.py:129-131, and the `loss` of fig2a/runners/graphsage_runners.py:43):
+ *   dw_l[n2, h2] += dz2[0:m2]^T . agg2[0:m2],   dw_r[n2, h2] += dz2[0:m2]^T . h_root2[0:m2]
+ *   (= sage_linear_dweight2 for n2 <= 64; rows limited by *m2_dev if given), and
+ *   loss[0] = mean(row_loss[0:m2]) in a fixed order if row_loss / loss are given —
+ * in workgroups of their own in front of the pass's: nothing they read is written by it (dz2,
+ * agg2, h_root2 must not alias dz / dh). */
+int sage_l2norm_relu_bwd_z_dw(float* dh, sage_i64 ld_dh, float* z, sage_i64 ld_z, int relu_mask, sage_i64 m,
+                              const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz, int clear_dh,
+                              const float* dz2, sage_i64 ld_dz2, sage_i64 m2, const sage_i64* m2_dev, int n2,
+                              int h2, const float* agg2, sage_i64 ld_agg2, float* dw_l, sage_i64 ld_dwl,
+                              const float* h_root2, sage_i64 ld_h_root2, float* dw_r, sage_i64 ld_dwr,
+                              const float* row_loss, float* loss, void* stream);
 
 /* Gradient through the ReLU of the pool Linear, relu(pool(x_j)) at layers/sage.py:202,206 — what
  * autograd's threshold_backward computes:  dz[r, :] = out[r, :] > 0 ? dout[r, :] : 0  for r < m
@@ -548,6 +563,18 @@ int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_pt
                          sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
                          const float* w_r, sage_i64 ld_wr, int n, float* dh, sage_i64 ld_dh,
                          const float* row_loss, float* loss, void* stream);
+/* Forward AND the input gradient of sage_logit_layer_bwd in ONE launch: every seed's wave runs
+ * its backward right behind its forward (a seed's input gradient needs nothing but its own dz;
+ * the weights are staged in LDS once).  Arguments as sage_logit_layer_fwd + dh; dz, agg, h_root
+ * and row_loss are still written for the weight gradients and the loss mean, which
+ * sage_l2norm_relu_bwd_z_dw (or sage_linear_dweight2 + a mean) supplies. */
+int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
+                             sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
+                             const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,
+                             const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
+                             float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
+                             float* row_loss, float* h_root, sage_i64 ld_h_root, float* dh, sage_i64 ld_dh,
+                             void* stream);
 /* sage_logit_layer_bwd with the layer's two weight gradients in the same launch (what
  * loss.backward() leaves in lin_l.weight.grad / lin_r.weight.grad of the last SAGE layer,
  * layers/sage.py:129-131):  dw_l[n, h] += dz[0:m]^T . agg[0:m],  dw_r[n, h] += dz[0:m]^T . h_root[0:m]

@@ -762,6 +762,36 @@ def test_logit_layer_on_preactivation_rows(dev, reduce, h, n):
     if h == 36:
         with pytest.raises(RuntimeError, match="aligned"):
             ops.l2norm_relu_bwd_z(dh.clone(), torch.zeros(n_src, 37, device=dev)[:, :36], True)
+    # the two-launch form of the layer's step: forward + input gradient in one launch
+    # (sage_logit_layer_fwd_bwd), then the hidden layer's pass with the weight gradients and the
+    # loss mean riding along (sage_l2norm_relu_bwd_z_dw) — against the separate calls
+    for pre in (True, False):
+        rows_in = z if pre else h_ref
+        agg3, y3, inv3, dz3, rl3 = bufs()
+        hr3 = torch.full((m, ldh), 7.0, device=dev)[:, :h] if pre else None
+        dh3 = torch.zeros(n_src, ldh, device=dev)[:, :h]
+        ops.logit_layer_fwd(rows_in, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg3, y3, inv3, dz3, rl3,
+                            h_root=hr3, dh=dh3)
+        torch.testing.assert_close(dz3, dz, rtol=1e-4, atol=1e-7)      # (another instantiation: fma contraction differs)
+        torch.testing.assert_close(agg3, agg if pre else agg2, rtol=1e-6, atol=1e-7)
+        dh_ref, loss_ref = torch.zeros_like(dh3), torch.zeros(1, device=dev)
+        ops.logit_layer_bwd(dz3, seg_ptr, src, m, reduce, w_l, w_r, dh_ref, rl3, loss_ref)
+        torch.testing.assert_close(dh3, dh_ref, rtol=1e-5, atol=1e-6)          # (atomics: any order)
+    gbuf = torch.randn(2 * n, ldh, generator=g, device=dev)
+    ref = gbuf.clone()
+    ops.linear_dweight2(dz, agg, ref[:n, :h], h_root, ref[n:, :h], m=m)
+    zc, dhc = z.clone(), dh.clone()
+    got = torch.zeros(n_src, ldh, device=dev)[:, :h]
+    loss = torch.zeros(1, device=dev)
+    ops.l2norm_relu_bwd_z_dw(dhc, zc, True, n_src, None, got, True, dz, m, None, agg, gbuf[:n, :h], h_root, gbuf[n:, :h],
+                             rl, loss)
+    torch.testing.assert_close(got, ops.l2norm_relu_bwd(dh.clone(), y_ref, inv_ref, True), rtol=1e-6, atol=1e-30)
+    assert float(zc.abs().max()) == 0.0 and float(dhc.abs().max()) == 0.0
+    torch.testing.assert_close(gbuf, ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(loss, rl[:m].double().mean().float().view(1), rtol=1e-6, atol=1e-7)
+    with pytest.raises(RuntimeError, match="must not be written"):
+        ops.l2norm_relu_bwd_z_dw(dhc, zc, True, n_src, None, got, True, dz, m, None, got, gbuf[:n, :h], h_root,
+                                 gbuf[n:, :h])
 
 
 def test_logit_layer_rejects_weights_beyond_lds(dev):
