@@ -378,6 +378,8 @@ class SageTrainEngine:
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
         self.cons_ev = [torch.cuda.Event(), torch.cuda.Event()]   # main stream finished a group
         self.started = torch.cuda.Event()    # main stream reached the start of a step
+        self._gate = self.started
+        self._own_gate = bool(os.environ.get('SAGE_STARTED_EVENT'))
         self.n_pref = 0         # batches prefetched so far; batch n lives in slot n % nslots
         self.n_comp = 0         # batches computed so far
         self.main_ready_seq = -1   # newest batch whose sampling the main stream has waited for
@@ -1018,7 +1020,15 @@ class SageTrainEngine:
             main.wait_event(self.ready[p])
             side_next = self.n_pref - i > 1
             if side_next:
-                self.started.record(main)
+                # the gate of the next batch's gather: the main stream has reached this step.  The
+                # event recorded behind the previous step's last kernel says the same (nothing but
+                # the wait above sits between the two) and is already there: one marker fewer in the
+                # main stream's queue per step.  SAGE_STARTED_EVENT=1: an event of its own.
+                if self.cons_rec_seq == i - 1 and self.cons_latest is not None and not self._own_gate:
+                    self._gate = self.cons_latest
+                else:
+                    self.started.record(main)
+                    self._gate = self.started
                 if not main_first:
                     self._gather_next(i, before_gather, after_gather, gather_events)
         else:
@@ -1084,7 +1094,7 @@ class SageTrainEngine:
     def _gather_next(self, i, before_gather, after_gather, gather_events):
         """overlap_gather: the layer-0 gather of batch i+1 on the side stream, released when the main
         stream has reached the start of step i (`started`)."""
-        self.side.wait_event(self.started)
+        self.side.wait_event(self._gate)
         q = (i + 1) % self.nslots
         self._side_gather(q, before_gather, after_gather, gather_events)
         self.ready[q].record(self.side)
