@@ -97,6 +97,8 @@ SIGNATURES = {
                                        c_int, _P, c_int64, _P, _P]),
     "sage_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_float, _P, _P, c_int, _P]),
+    "sage_adam_step_signal": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
+                                      c_float, c_float, _P, _P, c_int, _P, _P]),
 }
 
 _lib = None

@@ -807,11 +807,10 @@ extern "C" int sage_softmax_xent_rows(const float* logits, sage_i64 ld_logits, c
   return SAGE_OK;
 }
 
-extern "C" int sage_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
-                              sage_i64 numel, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, float grad_scale, const sage_i64* step_in,
-                              sage_i64* step_out, int zero_grad, void* stream_) {
-  hipStream_t stream = static_cast<hipStream_t>(stream_);
+static int adam_step_impl(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                          sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                          float weight_decay, float grad_scale, const sage_i64* step_in,
+                          sage_i64* step_out, int zero_grad, hipEvent_t done, hipStream_t stream) {
   SAGE_REQUIRE(numel >= 0, SAGE_EINVAL, "sage_adam_step: negative numel");
   SAGE_REQUIRE(step_in != nullptr && step_out != nullptr, SAGE_EINVAL, "sage_adam_step: step pointer is NULL");
   const bool in_place = step_in == step_out;
@@ -819,23 +818,45 @@ extern "C" int sage_adam_step(float* param, float* grad, float* exp_avg, float* 
     SAGE_REQUIRE(param && grad && exp_avg && exp_avg_sq, SAGE_EINVAL,
                  "sage_adam_step: NULL pointer argument");
     auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    // (done: attached to the launch as its completion event — the dispatch's own signal, no marker
+    // behind it in the queue; only where this launch is the call's last)
+    hipEvent_t stop = in_place ? nullptr : done;
     if (numel % 4 == 0 && numel >= (1 << 20) && a16(param) && a16(grad) && a16(exp_avg) && a16(exp_avg_sq)) {
-      adam4_kernel<<<static_cast<unsigned>(cdiv(numel / 4, kBlock)), kBlock, 0, stream>>>(
-          reinterpret_cast<float4*>(param), reinterpret_cast<float4*>(const_cast<float*>(grad)),
-          reinterpret_cast<float4*>(exp_avg), reinterpret_cast<float4*>(exp_avg_sq), numel / 4, lr, beta1, beta2, eps,
-          weight_decay, grad_scale, step_in, in_place ? nullptr : step_out, zero_grad);
+      hipExtLaunchKernelGGL(adam4_kernel, dim3(static_cast<unsigned>(cdiv(numel / 4, kBlock))), dim3(kBlock), 0, stream,
+                            nullptr, stop, 0, reinterpret_cast<float4*>(param),
+                            reinterpret_cast<float4*>(const_cast<float*>(grad)), reinterpret_cast<float4*>(exp_avg),
+                            reinterpret_cast<float4*>(exp_avg_sq), numel / 4, lr, beta1, beta2, eps, weight_decay,
+                            grad_scale, step_in, in_place ? nullptr : step_out, zero_grad);
     } else {
-      adam_kernel<<<static_cast<unsigned>(cdiv(numel, kBlock)), kBlock, 0, stream>>>(
-          param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale,
-          step_in, in_place ? nullptr : step_out, zero_grad);
+      hipExtLaunchKernelGGL(adam_kernel, dim3(static_cast<unsigned>(cdiv(numel, kBlock))), dim3(kBlock), 0, stream,
+                            nullptr, stop, 0, param, static_cast<const float*>(grad), exp_avg, exp_avg_sq, numel, lr,
+                            beta1, beta2, eps, weight_decay, grad_scale, step_in, in_place ? nullptr : step_out,
+                            zero_grad);
     }
     SAGE_CHECK_LAUNCH("adam_kernel");
   }
   if (in_place || numel == 0) {
-    bump_step2_kernel<<<1, 1, 0, stream>>>(step_in, step_out);
+    hipExtLaunchKernelGGL(bump_step2_kernel, dim3(1), dim3(1), 0, stream, nullptr, done, 0, step_in, step_out);
     SAGE_CHECK_LAUNCH("bump_step_kernel");
   }
   return SAGE_OK;
+}
+
+extern "C" int sage_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                              sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, float grad_scale, const sage_i64* step_in,
+                              sage_i64* step_out, int zero_grad, void* stream_) {
+  return adam_step_impl(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale, step_in,
+                        step_out, zero_grad, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int sage_adam_step_signal(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                     sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                                     float weight_decay, float grad_scale, const sage_i64* step_in,
+                                     sage_i64* step_out, int zero_grad, void* done_event, void* stream_) {
+  SAGE_REQUIRE(done_event != nullptr, SAGE_EINVAL, "sage_adam_step_signal: NULL event");
+  return adam_step_impl(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale, step_in,
+                        step_out, zero_grad, static_cast<hipEvent_t>(done_event), static_cast<hipStream_t>(stream_));
 }
 
 extern "C" int sage_logits_xent_fused(float* z, sage_i64 ld_z, const sage_i64* labels,

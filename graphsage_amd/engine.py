@@ -377,6 +377,9 @@ class SageTrainEngine:
         self.sampled = [torch.cuda.Event() for _ in range(self.nslots)]     # slot sampled (sampler stream)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
         self.cons_ev = [torch.cuda.Event(), torch.cuda.Event()]   # main stream finished a group
+        for ev in self.cons_ev:
+            ev.record()             # (creates the handle: the Adam launch can carry it as its completion event)
+        self._adam_signal = not os.environ.get('SAGE_NO_ADAM_SIGNAL')
         self.started = torch.cuda.Event()    # main stream reached the start of a step
         self._gate = self.started
         self._own_gate = bool(os.environ.get('SAGE_STARTED_EVENT'))
@@ -898,17 +901,21 @@ class SageTrainEngine:
         if self.collective:
             all_reduce_flat(self.grad, self.pg, force=True)
 
-    def optimizer_step(self):
+    def optimizer_step(self, signal=None):
+        """signal (0 / 1): cons_ev[signal] becomes the launch's completion event (no record() behind it)."""
         self._note('adam')
         par = self._adam_calls & 1
         self._adam_calls += 1
-        self._taped('adam', par, lambda: self._optimizer_step(par))
+        if signal is None:
+            self._taped('adam', par, lambda: self._optimizer_step(par))
+        else:
+            self._taped('adam_sig%d' % signal, par, lambda: self._optimizer_step(par, self.cons_ev[signal]))
 
-    def _optimizer_step(self, par):
+    def _optimizer_step(self, par, done_event=None):
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._steps[par:par + 1], self.lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
                       grad_scale=1.0 / self.world_size, step_out=self._steps[1 - par:2 - par],
-                      zero_grad=not self.keep_grads)
+                      zero_grad=not self.keep_grads, done_event=done_event)
 
     # ------------------------------------------------------------------ one batch at a time
     def step(self, seeds, counter=None, valid=None):
@@ -1013,6 +1020,7 @@ class SageTrainEngine:
         main = torch.cuda.current_stream()
         main_first = not self._side_first
         side_next = False
+        signalled = None
         if ov:
             if not self.gathered[p]:      # pipeline was drained below its depth
                 self._side_gather(p, None, None)
@@ -1073,7 +1081,13 @@ class SageTrainEngine:
                 if len(self._dp_events) > 2:
                     self._dp_events.pop(0).synchronize()
         else:
-            self.optimizer_step()
+            # the end-of-step event rides on the Adam launch as its completion event (one marker fewer
+            # in the main stream's queue; SAGE_NO_ADAM_SIGNAL=1: recorded behind it as before)
+            if (i + 1) % self.group == 0 and self._adam_signal:
+                signalled = (i // self.group) & 1
+                self.optimizer_step(signal=signalled)
+            else:
+                self.optimizer_step()
         if main_first:
             # the side streams' share of this call LAST: when the host is not ahead of the device
             # (the first step behind a synchronisation — a 20-step timing window starts with one —
@@ -1087,7 +1101,8 @@ class SageTrainEngine:
                 self.prefetch(next_seeds, next_counter)
         if (i + 1) % self.group == 0:
             ev = self.cons_ev[(i // self.group) & 1]
-            ev.record(main)
+            if signalled is None:
+                ev.record(main)
             self.cons_latest, self.cons_rec_seq = ev, i
         return self.loss
 

@@ -981,23 +981,31 @@ def logit_layer_bwd_dw(dz, seg_ptr, src, m, reduce, w_l, w_r, dh, agg, dw_l, h_r
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8,
-              weight_decay=0.0, grad_scale=1.0, step_out=None, zero_grad=False):
+              weight_decay=0.0, grad_scale=1.0, step_out=None, zero_grad=False, done_event=None):
     """torch.optim.Adam step on flat fp32 buffers.  The step count is read from step_dev
     (int64[1]) and count+1 written to step_out (default: step_dev itself, which costs a second
-    tiny kernel).  zero_grad=True clears grad after use."""
+    tiny kernel).  zero_grad=True clears grad after use.  done_event: a torch.cuda.Event that has
+    been recorded at least once (its handle exists) — attached to the launch as its completion
+    event instead of a record() behind it (sage_adam_step_signal)."""
     lib = _lib.load()
     n = param.numel()
     for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
         if t.numel() != n or not t.is_contiguous():
             raise RuntimeError(f"adam_step: {name} must be contiguous with {n} elements")
-    rc = lib.sage_adam_step(_p(param, torch.float32, "param"), _p(grad, torch.float32, "grad"),
-                            _p(exp_avg, torch.float32, "exp_avg"),
-                            _p(exp_avg_sq, torch.float32, "exp_avg_sq"), n, float(lr), float(beta1),
-                            float(beta2), float(eps), float(weight_decay), float(grad_scale),
-                            _count(step_dev, "step_dev"),
-                            _count(step_dev if step_out is None else step_out, "step_out"),
-                            1 if zero_grad else 0, _stream())
-    _lib.check(rc, "sage_adam_step")
+    args = (_p(param, torch.float32, "param"), _p(grad, torch.float32, "grad"),
+            _p(exp_avg, torch.float32, "exp_avg"),
+            _p(exp_avg_sq, torch.float32, "exp_avg_sq"), n, float(lr), float(beta1),
+            float(beta2), float(eps), float(weight_decay), float(grad_scale),
+            _count(step_dev, "step_dev"),
+            _count(step_dev if step_out is None else step_out, "step_out"),
+            1 if zero_grad else 0)
+    if done_event is None:
+        _lib.check(lib.sage_adam_step(*args, _stream()), "sage_adam_step")
+        return
+    handle = done_event.cuda_event
+    if not handle:
+        raise RuntimeError("adam_step: done_event has no handle yet (record it once first)")
+    _lib.check(lib.sage_adam_step_signal(*args, ctypes.c_void_p(handle), _stream()), "sage_adam_step_signal")
 
 
 # ------------------------------------------------------------------------------- a-7

@@ -620,6 +620,14 @@ int sage_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
                    sage_i64 numel, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float grad_scale, const sage_i64* step_in,
                    sage_i64* step_out, int zero_grad, void* stream);
+/* The same step with a HIP event (hipEvent_t) attached to its launch as the completion event
+ * (hipExtLaunchKernelGGL's stop event): other streams can hipStreamWaitEvent on it as if it had
+ * been recorded behind the kernel, without a marker in this stream's queue — the engine's
+ * end-of-step signal for the sampler / gather streams.  No counterpart in the reference. */
+int sage_adam_step_signal(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                   sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float grad_scale, const sage_i64* step_in,
+                   sage_i64* step_out, int zero_grad, void* done_event, void* stream);
 
 #ifdef __cplusplus
 }
