@@ -197,6 +197,7 @@ class SageTrainEngine:
         # loss mean ride in front of the hidden layer's normalise-backward pass
         # (sage_l2norm_relu_bwd_z_dw).  SAGE_NO_LOGIT_FWDBWD=1: forward and backward launches apart.
         self.logit_fwdbwd = self.prenorm and self.fused_logit_dw and not os.environ.get('SAGE_NO_LOGIT_FWDBWD')
+        self.writers = None         # per sample slot, filled in below once the buffers exist
         self.features, self.labels = features, labels
         self.B = int(batch_size)
         self.L = len(model.layers)
@@ -234,6 +235,9 @@ class SageTrainEngine:
                      for _ in range(self.nslots)]
         self.ctrl = torch.zeros(ops.CTRL_WORDS, dtype=torch.int64, device=dev)
         self._stamp = 0
+        if self.logit_fwdbwd and not os.environ.get('SAGE_NO_SOLO_ROWS'):
+            # writers per row of the hidden layer's gradient (rows = the targets of layer L-2), per slot
+            self.writers = [torch.zeros(self.hop_cap[1], dtype=torch.int32, device=dev) for _ in range(self.nslots)]
         # device-side row counts per slot: n_dev[slot][h] = #nodes after hop h
         self.n_dev = [[b.state[ops.ST_HOP_NODES + h: ops.ST_HOP_NODES + h + 1] for h in range(self.L + 1)]
                       for b in self.bufs]
@@ -422,6 +426,7 @@ class SageTrainEngine:
             ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed, counter,
                               self.table, 1, self.bufs[slot], ctrl=ctrl, num_seeds=self.B)
             ops.state_accumulate(self.bufs[slot].state, self.state_sum)
+            self._count_writers(slot)
             return
         self._next_stamp(stream)
         if self.unsup:
@@ -435,25 +440,35 @@ class SageTrainEngine:
                 ops.sample_fanout(self.graph.colptr, self.graph.row, seeds, self.fanout, self.rng_seed,
                                   counter, self.table, self._stamp, self.bufs[slot], num_seeds=self.B)
                 ops.state_accumulate(self.bufs[slot].state, self.state_sum)
+                self._count_writers(slot)
             if stream is not None and stream != torch.cuda.current_stream():
                 with torch.cuda.stream(stream), _lib.recording() as tape:
                     first()
             else:
                 with _lib.recording() as tape:
                     first()
-            (fn, args, name), acc = tape
-            self._tapes[key] = (fn, list(args), name, acc)
+            (fn, args, name), acc = tape[:2]
+            self._tapes[key] = (fn, list(args), name, acc, tape[2:])
             return
         # later calls: same pointers except the seeds, the Philox counter and the stamp
         if not (seeds.is_cuda and seeds.dtype == torch.int64 and seeds.dim() == 1 and seeds.is_contiguous()
                 and seeds.numel() >= self.B):
             raise RuntimeError("sample: seeds must be a contiguous CUDA int64 vector of at least B elements")
-        fn, args, name, acc = entry
+        fn, args, name, acc, rest = entry
         args[3] = seeds.data_ptr()
         args[8] = int(counter) & 0xFFFFFFFFFFFFFFFF
         args[10] = self._stamp
         _lib.check(fn(*args), name)
         _lib.check(acc[0](*acc[1]), acc[2])      # state_sum += this batch's sizes, same stream
+        if rest:
+            _lib.replay(rest)                    # (the class-logit layer's writer counts)
+
+    def _count_writers(self, slot):
+        """Behind the sampler, on its stream: how many seed waves will add into each row of the
+        hidden layer's gradient (sage_logit_layer_fwd_bwd stores the rows with one writer)."""
+        if self.writers is not None:
+            buf = self.bufs[slot]
+            ops.count_row_writers(buf.seg_ptr, buf.src, self.B, self.writers[slot], max_edges=self.B * max(self.fanout[0], 1))
 
     def _next_stamp(self, stream=None):
         """Stamps of the relabel table must grow (sage_hip.h); when the 32-bit range is used up,
@@ -720,7 +735,8 @@ class SageTrainEngine:
             lib.logit_layer_fwd(prev['z'] if self.prenorm else prev['h'], buf.seg_ptr, buf.src, B, self.reduce,
                                 layer.lin_l.weight, layer.lin_r.weight, self.labels, buf.node, last['agg'], last['y'],
                                 last['inv'], last['dz'], self.row_loss, h_root=prev['h'] if self.prenorm else None,
-                                dh=prev['dh'] if self.logit_fwdbwd else None)
+                                dh=prev['dh'] if self.logit_fwdbwd else None,
+                                writers=self.writers[slot] if (self.logit_fwdbwd and self.writers is not None) else None)
             return
         if not self.unsup:
             self._forward_layers(slot, 0, skip_gather0)

@@ -865,14 +865,16 @@ def logit_layer_supported(h, n):
 
 
 def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_rows, agg, y, inv_norm, dz,
-                    row_loss, grad_scale=1.0, h_root=None, dh=None):
+                    row_loss, grad_scale=1.0, h_root=None, dh=None, writers=None):
     """The last SAGE layer on the m seed rows + normalise + cross entropy + d loss / d z in one
     launch (reference layers/sage.py:99-134 + fig2a/runners/graphsage_runners.py:41-43); all
     buffers are the caller's (static-shape engine).  agg [m, h] is kept for the weight gradients.
     h_root [>= m, h]: h_rows holds the previous layer's PRE-activation rows; the kernel takes
     every row through relu(normalize(.)) itself and stores the seeds' activations there.
     dh [rows of h_rows, h]: the layer's input gradient is added to it in the same launch
-    (sage_logit_layer_fwd_bwd = this + logit_layer_bwd without the loss mean)."""
+    (sage_logit_layer_fwd_bwd = this + logit_layer_bwd without the loss mean); writers (int32, one
+    per row of dh, from count_row_writers): rows with one writer are stored instead of added —
+    dh must then hold zeros."""
     lib = _lib.load()
     hp, ld_h = _mat(h_rows, "h_rows")
     wlp, ld_wl = _mat(w_l, "w_l")
@@ -902,7 +904,24 @@ def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_row
     gp, ld_dh = _mat(dh, "dh")
     if dh.size(1) != h or dh.size(0) < h_rows.size(0):
         raise RuntimeError("logit_layer_fwd: dh must cover the rows of h_rows")
-    _lib.check(lib.sage_logit_layer_fwd_bwd(*args, gp, ld_dh, _stream()), "sage_logit_layer_fwd_bwd")
+    if writers is not None and (writers.dtype != torch.int32 or writers.numel() < dh.size(0) or not writers.is_contiguous()):
+        raise RuntimeError("logit_layer_fwd: writers must be a contiguous int32 tensor with one entry per row of dh")
+    _lib.check(lib.sage_logit_layer_fwd_bwd(*args, gp, ld_dh, _p(writers, torch.int32, "writers", allow_none=True),
+                                            _stream()), "sage_logit_layer_fwd_bwd")
+
+
+def count_row_writers(seg_ptr, src, m, writers, max_edges=None):
+    """writers[r] = number of edges of the first m segments whose source is row r, + 1 for r < m
+    (sage_count_row_writers; what logit_layer_fwd(dh=..., writers=...) wants)."""
+    lib = _lib.load()
+    m = int(m)
+    if writers.dtype != torch.int32 or not writers.is_contiguous() or writers.numel() < m or seg_ptr.numel() < m + 1:
+        raise RuntimeError("count_row_writers: bad buffers")
+    rc = lib.sage_count_row_writers(_vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), m,
+                                    int(src.numel() if max_edges is None else max_edges),
+                                    _p(writers, torch.int32, "writers"), writers.numel(), _stream())
+    _lib.check(rc, "sage_count_row_writers")
+    return writers
 
 
 def logit_layer_infer(h_rows, seg_ptr, src, m, reduce, w_l, w_r, y=None, pred=None, pre_activation=False):

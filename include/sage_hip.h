@@ -574,7 +574,17 @@ int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, const sage_i64*
                              const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
                              float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz,
                              float* row_loss, float* h_root, sage_i64 ld_h_root, float* dh, sage_i64 ld_dh,
+                             const int* writers /* NULL, or sage_count_row_writers' output for these segments:
+                                                   rows of dh with ONE writer are stored instead of added
+                                                   (dh must then hold zeros on entry) */,
                              void* stream);
+/* writers[r] (int32, r < rows) = the number of waves of sage_logit_layer_fwd_bwd that add into row r
+ * of dh: the edges e in [seg_ptr[0], seg_ptr[m]) with src[e] == r, plus one for r < m (a seed's
+ * own row).  max_edges bounds seg_ptr[m] - seg_ptr[0] (the launch is sized by it).  Two short
+ * launches; the engine runs them behind the sampler on its stream.  No counterpart in the
+ * reference (torch_scatter adds every edge atomically). */
+int sage_count_row_writers(const sage_i64* seg_ptr, const sage_i64* src, sage_i64 m, sage_i64 max_edges,
+                           int* writers, sage_i64 rows, void* stream);
 /* sage_logit_layer_bwd with the layer's two weight gradients in the same launch (what
  * loss.backward() leaves in lin_l.weight.grad / lin_r.weight.grad of the last SAGE layer,
  * layers/sage.py:129-131):  dw_l[n, h] += dz[0:m]^T . agg[0:m],  dw_r[n, h] += dz[0:m]^T . h_root[0:m]

@@ -4,6 +4,10 @@
 #define SAGE_LOGIT_PROF 1
 #include "../graphsage_amd/csrc/logit.hip"
 #include "../graphsage_amd/csrc/api.hip"
+// (logit.hip's fallback for weights beyond the LDS calls into linear.hip, which this harness does not link)
+extern "C" int sage_linear_dweight2(const float*, sage_i64, const float*, sage_i64, const sage_i64*, int, float*, sage_i64,
+                                    const float*, sage_i64, const sage_i64*, int, float*, sage_i64, sage_i64,
+                                    const sage_i64*, int, void*) { return SAGE_EINVAL; }
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -32,6 +36,7 @@ int main() {
   const bool pre = getenv("PRE") != nullptr;      // PRE=1: the rows are pre-activation rows, normalised on their way in
   auto fwd = [&]() { return sage_logit_layer_fwd(dh_, H, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dlab, nullptr, 1.f, agg, H, y, 64, inv, dz, 64, rl, pre ? hroot : nullptr, H, nullptr); };
   auto bwd = [&]() { return sage_logit_layer_bwd(dz, 64, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dgrad, H, rl, loss, nullptr); };
+  auto fb = [&]() { return sage_logit_layer_fwd_bwd(dh_, H, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dlab, nullptr, 1.f, agg, H, y, 64, inv, dz, 64, rl, pre ? hroot : nullptr, H, dgrad, H, nullptr); };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms;
   for (int rep = 0; rep < 2; ++rep) {
@@ -40,6 +45,15 @@ int main() {
     CK(hipEventElapsedTime(&ms, e0, e1)); printf("fwd %.1f us\n", ms * 20);
     CK(hipEventRecord(e0)); for (int i = 0; i < 50; ++i) SK(bwd()); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     CK(hipEventElapsedTime(&ms, e0, e1)); printf("bwd %.1f us\n", ms * 20);
+  }
+  for (int i = 0; i < 5; ++i) SK(fb());
+  CK(hipEventRecord(e0)); for (int i = 0; i < 50; ++i) SK(fb()); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1)); printf("fwd+bwd in one launch %.1f us\n", ms * 20);
+  {
+    unsigned long long s2[2][16];
+    CK(hipMemcpyFromSymbol(s2, HIP_SYMBOL(sage::g_logit_prof), sizeof(s2)));
+    printf("fwd+bwd stamps (x10 ns): "); for (int i = 1; i <= 7; ++i) printf("%lld ", (long long)(s2[0][i] - s2[0][0])); printf("\n");
+    for (int i = 0; i < 3; ++i) { SK(fwd()); SK(bwd()); }
   }
   unsigned long long st[2][16];
   CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(sage::g_logit_prof), sizeof(st)));

@@ -777,6 +777,19 @@ def test_logit_layer_on_preactivation_rows(dev, reduce, h, n):
         dh_ref, loss_ref = torch.zeros_like(dh3), torch.zeros(1, device=dev)
         ops.logit_layer_bwd(dz3, seg_ptr, src, m, reduce, w_l, w_r, dh_ref, rl3, loss_ref)
         torch.testing.assert_close(dh3, dh_ref, rtol=1e-5, atol=1e-6)          # (atomics: any order)
+        # ... and with the rows that have ONE writer stored instead of added (sage_count_row_writers)
+        writers = torch.full((n_src,), -7, dtype=torch.int32, device=dev)
+        ops.count_row_writers(seg_ptr, src, m, writers)
+        want_w = torch.bincount(src, minlength=n_src).int()
+        want_w[:m] += 1
+        assert torch.equal(writers, want_w)
+        assert int((writers == 1).sum()) > 20 and int((writers > 1).sum()) > 20      # both routes are exercised
+        dh4 = torch.zeros_like(dh3)
+        ops.logit_layer_fwd(rows_in, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg3, y3, inv3, dz3, rl3,
+                            h_root=hr3, dh=dh4, writers=writers)
+        torch.testing.assert_close(dh4, dh_ref, rtol=1e-5, atol=1e-6)
+        solo = writers == 1
+        assert torch.equal(dh4[solo], dh3[solo])                                  # one writer either way: same bits
     gbuf = torch.randn(2 * n, ldh, generator=g, device=dev)
     ref = gbuf.clone()
     ops.linear_dweight2(dz, agg, ref[:n, :h], h_root, ref[n:, :h], m=m)
