@@ -55,6 +55,8 @@ SIGNATURES = {
                                     _P, c_int64, _P, _P]),
     "sage_linear_dweight2": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, c_int64,
                                      _P, c_int64, _P, c_int, _P, c_int64, c_int64, _P, c_int, _P]),
+    "sage_linear_dweight2_parts": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, c_int64,
+                                     _P, c_int64, _P, c_int, _P, c_int64, c_int64, _P, c_int, c_int64, c_int, _P, _P]),
     "sage_segment_slots": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P, _P]),
     "sage_lstm_cell0_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, _P, _P, _P, c_int64, _P]),
     "sage_lstm_cell0_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int64, _P, c_int, _P, _P, _P, c_int64, _P]),
@@ -98,6 +100,8 @@ SIGNATURES = {
                                        c_int, _P, c_int64, _P, _P]),
     "sage_adam_step": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                c_float, c_float, _P, _P, c_int, _P]),
+    "sage_adam_step_parts": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
+                                     c_float, c_float, _P, _P, c_int, _P, c_int64, c_int, c_int64, c_int64, _P, _P]),
     "sage_adam_step_signal": (c_int, [_P, _P, _P, _P, c_int64, c_float, c_float, c_float, c_float,
                                       c_float, c_float, _P, _P, c_int, _P, _P]),
 }

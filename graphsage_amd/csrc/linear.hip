@@ -96,6 +96,11 @@ struct GemmArgs {
   // neighbouring pieces of the problem, so that operand pieces several of them need are fetched
   // into that XCD's L2 once (SAGE_GEMM_XCD=0 keeps the plain order: A/B switch)
   int xcd_map;
+  // weight gradients (gemm_x3_dw_kernel) only: > 0 — split-K slice z STORES its partial tile at
+  // out + z * part_stride (out2 likewise) instead of adding it into out with fp32 atomics; the
+  // consumer sums the slices (sage_adam_step_parts).  fp32 atomics run at ~1.2 TB/s chip-wide, a
+  // sixth of plain stores: 25 slices x 1.2 MB cost the headline's launch 10 of its 64 us.
+  int64_t part_stride;
 };
 
 // ---- global -> register staging of one operand tile ---------------------------------
@@ -1127,7 +1132,17 @@ __global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_dw_kernel(
     k_beg = bz * chunk;
     k_end = k_beg + chunk < k_lim ? k_beg + chunk : k_lim;
   }
-  if (m0 >= m_lim || k_beg >= k_end) return;   // block-uniform: EXEC stays full for the transposing reads
+  if (m0 >= m_lim) return;                     // block-uniform: EXEC stays full for the transposing reads
+  if (k_beg >= k_end) {
+    if (g.part_stride > 0) {                   // an empty slice still owns its partial tile: zeros
+      float* zp = out_p + static_cast<int64_t>(bz) * g.part_stride;
+      for (int idx = threadIdx.x; idx < BM * BN; idx += kThreads) {
+        const int64_t r = m0 + idx / BN, c = n0 + idx % BN;
+        if (r < m_lim && c < n_lim) zp[r * ld_out_p + c] = 0.f;
+      }
+    }
+    return;
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r16 = lane & 15, kg = lane >> 4;     // 16x16x32 operand: column r16, k = 8 kg .. 8 kg + 7
@@ -1246,9 +1261,17 @@ __global__ void __launch_bounds__(kThreads, BM == 64 ? 3 : 2) gemm_x3_dw_kernel(
       const int64_t col = n0 + wn0 + j * 16 + r16;
       const int64_t row0 = m0 + wm0 + i * 16 + 4 * kg;
       float* base = out_p + row0 * ld_out_p + col;
+      if (g.part_stride > 0) {      // (uniform) this slice's own copy of the tile: plain stores
+        base += static_cast<int64_t>(bz) * g.part_stride;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (col < n_lim && row0 + e < m_lim) atomicAdd(base + e * ld_out_p, acc[i][j][e]);
+        for (int e = 0; e < 4; ++e) {
+          if (col < n_lim && row0 + e < m_lim) base[e * ld_out_p] = acc[i][j][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (col < n_lim && row0 + e < m_lim) atomicAdd(base + e * ld_out_p, acc[i][j][e]);
+        }
       }
     }
 }
@@ -1717,12 +1740,14 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   return launch_gemm<false, false>(g, static_cast<int>(splits), stream, "gemm_kernel(dweight)");
 }
 
-extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1,
-                                    sage_i64 ld_a1, const sage_i64* rows1, int k1, float* dw1,
-                                    sage_i64 ld_dw1, const float* a2, sage_i64 ld_a2,
-                                    const sage_i64* rows2, int k2, float* dw2, sage_i64 ld_dw2,
-                                    sage_i64 m, const sage_i64* m_dev, int n, void* stream_) {
+static int linear_dweight2_impl(const float* dout, sage_i64 ld_dout, const float* a1,
+                                sage_i64 ld_a1, const sage_i64* rows1, int k1, float* dw1,
+                                sage_i64 ld_dw1, const float* a2, sage_i64 ld_a2,
+                                const sage_i64* rows2, int k2, float* dw2, sage_i64 ld_dw2,
+                                sage_i64 m, const sage_i64* m_dev, int n, sage_i64 part_stride, int max_parts,
+                                int* parts_out, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
+  if (parts_out != nullptr) *parts_out = 1;       // unless the sliced path below is taken: sums in dw1 / dw2
   SAGE_REQUIRE(m >= 0 && n > 0 && k1 > 0 && k2 > 0 && ld_dout >= n && ld_a1 >= k1 && ld_a2 >= k2 &&
                    ld_dw1 >= k1 && ld_dw2 >= k2,
                SAGE_EINVAL, "sage_linear_dweight2: bad shape (m=%lld n=%d k1=%d k2=%d)", (long long)m,
@@ -1787,6 +1812,10 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
       int64_t sp = balanced_splits(tiles2, 512, max_splits);
       g.k_chunk = static_cast<int>(cdiv(cdiv(m, sp), BK) * BK);
       sp = cdiv(m, g.k_chunk);
+      if (parts_out != nullptr && sp > 1 && sp <= max_parts) {
+        g.part_stride = part_stride;
+        *parts_out = static_cast<int>(sp);
+      }
       const dim3 grid(static_cast<unsigned>(cdiv(n, 128)), static_cast<unsigned>(g.ny0 + cdiv(k2, 128)),
                       static_cast<unsigned>(sp));
       SAGE_LAUNCH_PROBED((gemm_x3_dw_kernel<128>), grid, kThreads, stream, g);
@@ -1799,4 +1828,25 @@ extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const f
     return SAGE_OK;
   }
   return launch_gemm<false, false>(g, static_cast<int>(splits), stream, "gemm_kernel(dweight2)");
+}
+
+extern "C" int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1,
+                                    sage_i64 ld_a1, const sage_i64* rows1, int k1, float* dw1,
+                                    sage_i64 ld_dw1, const float* a2, sage_i64 ld_a2,
+                                    const sage_i64* rows2, int k2, float* dw2, sage_i64 ld_dw2,
+                                    sage_i64 m, const sage_i64* m_dev, int n, void* stream_) {
+  return linear_dweight2_impl(dout, ld_dout, a1, ld_a1, rows1, k1, dw1, ld_dw1, a2, ld_a2, rows2, k2, dw2, ld_dw2, m, m_dev,
+                              n, 0, 0, nullptr, stream_);
+}
+
+extern "C" int sage_linear_dweight2_parts(const float* dout, sage_i64 ld_dout, const float* a1,
+                                          sage_i64 ld_a1, const sage_i64* rows1, int k1, float* dw1,
+                                          sage_i64 ld_dw1, const float* a2, sage_i64 ld_a2,
+                                          const sage_i64* rows2, int k2, float* dw2, sage_i64 ld_dw2,
+                                          sage_i64 m, const sage_i64* m_dev, int n, sage_i64 part_stride,
+                                          int max_parts, int* parts, void* stream_) {
+  SAGE_REQUIRE(parts != nullptr && max_parts >= 1 && part_stride > 0, SAGE_EINVAL,
+               "sage_linear_dweight2_parts: parts is NULL, max_parts < 1 or part_stride <= 0");
+  return linear_dweight2_impl(dout, ld_dout, a1, ld_a1, rows1, k1, dw1, ld_dw1, a2, ld_a2, rows2, k2, dw2, ld_dw2, m, m_dev,
+                              n, part_stride, max_parts, parts, stream_);
 }

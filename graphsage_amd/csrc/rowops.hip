@@ -559,6 +559,51 @@ __global__ void adam_kernel(float* __restrict__ param, const float* grad,
   if (zero_grad) const_cast<float*>(grad)[i] = 0.f;
 }
 
+// The same update where the gradient of one contiguous region [off, off + len) of the flat buffer
+// comes as `parts` partial sums ws[s * stride + (i - off)], s < parts (sage_linear_dweight2_parts:
+// the split-K slices of the layer-0 weight gradients, stored instead of added): summed here in slice
+// order, grad[i] is neither read nor written for those elements.
+__global__ void __launch_bounds__(kBlock)
+adam_parts_kernel(float* __restrict__ param, float* __restrict__ grad, float* __restrict__ exp_avg,
+                  float* __restrict__ exp_avg_sq, int64_t numel, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, float grad_scale, const int64_t* __restrict__ step_in,
+                  int64_t* __restrict__ step_out, int zero_grad, float* __restrict__ ws, int64_t stride,
+                  int parts, int64_t off, int64_t len) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t step = *step_in;
+  if (i == 0 && step_out != nullptr) *step_out = step + 1;
+  if (i >= numel) return;
+  float g;
+  const int64_t r = i - off;
+  if (r >= 0 && r < len) {
+    float* wp = ws + r;
+    g = 0.f;
+    int sidx = 0;
+    for (; sidx + 4 <= parts; sidx += 4) {      // four slices in flight
+      const float a0 = wp[(sidx + 0) * stride], a1 = wp[(sidx + 1) * stride], a2 = wp[(sidx + 2) * stride],
+                  a3 = wp[(sidx + 3) * stride];
+      g += a0; g += a1; g += a2; g += a3;
+    }
+    for (; sidx < parts; ++sidx) g += wp[sidx * stride];
+    if (parts == 1 && zero_grad) wp[0] = 0.f;      // (one part: the producer ADDS into it, as into grad)
+  } else {
+    g = grad[i];
+    if (zero_grad) grad[i] = 0.f;
+  }
+  g *= grad_scale;
+  const float t = static_cast<float>(step + 1);
+  const float bc1 = 1.f - powf(beta1, t);
+  const float bc2 = 1.f - powf(beta2, t);
+  const float p = param[i];
+  if (weight_decay != 0.f) g += weight_decay * p;
+  const float m1 = beta1 * exp_avg[i] + (1.f - beta1) * g;
+  const float v1 = beta2 * exp_avg_sq[i] + (1.f - beta2) * g * g;
+  exp_avg[i] = m1;
+  exp_avg_sq[i] = v1;
+  const float denom = sqrtf(v1) / sqrtf(bc2) + eps;
+  param[i] = p - (lr / bc1) * (m1 / denom);
+}
+
 // The same update, four elements per thread with 16-byte accesses (numel a multiple of 4, all
 // four buffers 16-byte aligned: the engine's flat buffers are): the lstm model's 45 M parameters
 // are eight streams of 180 MB per step — 479 us one float at a time.  Per element the arithmetic
@@ -848,6 +893,26 @@ extern "C" int sage_adam_step(float* param, float* grad, float* exp_avg, float* 
                               sage_i64* step_out, int zero_grad, void* stream_) {
   return adam_step_impl(param, grad, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, weight_decay, grad_scale, step_in,
                         step_out, zero_grad, nullptr, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int sage_adam_step_parts(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                    sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                                    float weight_decay, float grad_scale, const sage_i64* step_in,
+                                    sage_i64* step_out, int zero_grad, float* ws, sage_i64 part_stride,
+                                    int parts, sage_i64 region_off, sage_i64 region_len, void* done_event,
+                                    void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(numel > 0 && param && grad && exp_avg && exp_avg_sq && step_in && step_out && step_in != step_out,
+               SAGE_EINVAL, "sage_adam_step_parts: NULL pointer, empty buffer or step_in == step_out");
+  SAGE_REQUIRE(ws && parts >= 1 && region_off >= 0 && region_len > 0 && region_off + region_len <= numel &&
+                   part_stride >= region_len,
+               SAGE_EINVAL, "sage_adam_step_parts: bad partial-sum region");
+  hipExtLaunchKernelGGL(adam_parts_kernel, dim3(static_cast<unsigned>(cdiv(numel, kBlock))), dim3(kBlock), 0, stream,
+                        nullptr, static_cast<hipEvent_t>(done_event), 0, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1,
+                        beta2, eps, weight_decay, grad_scale, step_in, step_out, zero_grad, ws, part_stride, parts,
+                        region_off, region_len);
+  SAGE_CHECK_LAUNCH("adam_parts_kernel");
+  return SAGE_OK;
 }
 
 extern "C" int sage_adam_step_signal(float* param, float* grad, float* exp_avg, float* exp_avg_sq,

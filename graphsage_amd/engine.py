@@ -30,6 +30,7 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
     is never re-laid, its gradient goes straight into the flat gradient, Adam is the fused kernel.
 """
 import contextlib
+import ctypes
 import os
 import time
 
@@ -267,6 +268,27 @@ class SageTrainEngine:
         # the same three forwards, loss = the unsupervised term alone (BASELINE.json configs[4])
         self.unsup = bool(unsup)
         self.unsup_only = unsup == 'only'
+        # Layer-0 weight gradients without atomics (one GPU, supervised step): the split-K slices of
+        # the launch STORE their partial tiles into a workspace of their own and Adam sums them while
+        # it reads them (sage_linear_dweight2_parts / sage_adam_step_parts) — fp32 atomics run at a
+        # sixth of the plain-store rate and cost that launch 10 of its 64 us.  The
+        # flat gradient then holds NOTHING for those two matrices: not under a collective (the
+        # all-reduce wants the sums) and not with keep_grads.  SAGE_NO_DW_PARTS=1: atomics.
+        self.dw_parts = None
+        if (not self.collective and not self.keep_grads and not self.unsup and not self.pool and not self.lstm
+                and self.root and not os.environ.get('SAGE_NO_DW_PARTS')):
+            params = list(model.parameters())
+            l0 = model.layers[0]
+            ia, ib = (next(k for k, q in enumerate(params) if q is w) for w in (l0.lin_l.weight, l0.lin_r.weight))
+            (oa, na, sha, lda), (ob, nb, shb, ldb) = self.layout[ia], self.layout[ib]
+            lo, hi = min(oa, ob), max(oa + na, ob + nb)
+            if hi - lo == na + nb and lda is not None and ldb is not None:      # one region of the flat buffer
+                max_parts = 32
+                ws = torch.zeros(max_parts * (hi - lo), dtype=torch.float32, device=dev)
+                self.dw_parts = dict(ws=ws, stride=hi - lo, off=lo, len=hi - lo, max=max_parts, n=0,
+                                     holder=ctypes.c_int(0),      # (written by every replay of the recorded call)
+                                     view_l=ws[oa - lo:oa - lo + na].view(sha[0], lda)[:, :sha[1]],
+                                     view_r=ws[ob - lo:ob - lo + nb].view(shb[0], ldb)[:, :shb[1]])
         nvar = 3 if self.unsup else 1
 
         def make_act():
@@ -816,7 +838,11 @@ class SageTrainEngine:
                                        x_in, self.gviews[layer.lin_r.weight], self.row_loss, self.loss, m_dev=t_dev)
                 continue
             with self._leaf(t_cap):
-                if self.root:
+                if self.root and i == 0 and self.dw_parts is not None:
+                    d = self.dw_parts
+                    d['n'] = lib.linear_dweight2_parts(a['dz'], agg_i, d['view_l'], x_in, d['view_r'], d['stride'], d['max'],
+                                                       d['holder'], m=t_cap, m_dev=t_dev, rows2=rows)
+                elif self.root:
                     lib.linear_dweight2(a['dz'], agg_i, self.gviews[layer.lin_l.weight], x_in,
                                         self.gviews[layer.lin_r.weight], m=t_cap, m_dev=t_dev, rows2=rows)
                 else:
@@ -928,10 +954,12 @@ class SageTrainEngine:
             self._taped('adam_sig%d' % signal, par, lambda: self._optimizer_step(par, self.cons_ev[signal]))
 
     def _optimizer_step(self, par, done_event=None):
+        d = self.dw_parts
+        parts = (d['ws'], d['stride'], d['n'], d['off'], d['len']) if (d is not None and d['n'] > 0) else None
         ops.adam_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self._steps[par:par + 1], self.lr,
                       self.betas[0], self.betas[1], self.eps, self.weight_decay,
                       grad_scale=1.0 / self.world_size, step_out=self._steps[1 - par:2 - par],
-                      zero_grad=not self.keep_grads, done_event=done_event)
+                      zero_grad=not self.keep_grads, done_event=done_event, parts=parts)
 
     # ------------------------------------------------------------------ one batch at a time
     def step(self, seeds, counter=None, valid=None):

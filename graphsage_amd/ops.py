@@ -561,6 +561,37 @@ def linear_dweight2(dout, a1, dw1, a2, dw2, m=None, m_dev=None, rows1=None, rows
     _lib.check(rc, "sage_linear_dweight2")
 
 
+def linear_dweight2_parts(dout, a1, dw1, a2, dw2, part_stride, max_parts, holder, m=None, m_dev=None, rows1=None,
+                          rows2=None):
+    """linear_dweight2 whose split-K slices STORE their partial sums at dw1 / dw2 + z * part_stride
+    floats where the launch allows it; returns the number of parts (1: the sums were added into
+    dw1 / dw2 as usual).  The caller owns max_parts * part_stride floats behind dw1's storage, and
+    `holder`, a ctypes.c_int that outlives every replay of the recorded call (the C side writes the
+    number of parts through its address)."""
+    lib = _lib.load()
+    dp, ld_dout = _mat(dout, "dout")
+    a1p, ld_a1 = _mat(a1, "a1")
+    a2p, ld_a2 = _mat(a2, "a2")
+    w1p, ld_dw1 = _mat(dw1, "dw1")
+    w2p, ld_dw2 = _mat(dw2, "dw2")
+    n, k1, k2 = dout.size(1), a1.size(1), a2.size(1)
+    if m is None:
+        m = dout.size(0)
+    m = int(m)
+    if dout.size(0) < m or (rows1 is None and a1.size(0) < m) or (rows2 is None and a2.size(0) < m) or \
+            dw1.shape != (n, k1) or dw2.shape != (n, k2) or part_stride <= 0 or max_parts < 1:
+        raise RuntimeError("linear_dweight2_parts: shape mismatch")
+    if not isinstance(holder, ctypes.c_int):
+        raise RuntimeError("linear_dweight2_parts: holder must be a ctypes.c_int kept alive by the caller")
+    parts = holder
+    rc = lib.sage_linear_dweight2_parts(dp, ld_dout, a1p, ld_a1, _rows(rows1, m, "rows1"), k1, w1p, ld_dw1,
+                                        a2p, ld_a2, _rows(rows2, m, "rows2"), k2, w2p, ld_dw2, m,
+                                        _count(m_dev, "m_dev"), n, int(part_stride), int(max_parts),
+                                        ctypes.addressof(parts), _stream())
+    _lib.check(rc, "sage_linear_dweight2_parts")
+    return parts.value
+
+
 # ------------------------------------------------------------------------------- rows
 def l2norm_relu_fwd(z, relu, m=None, m_dev=None, y=None, h=None, inv_norm=None, clear_z=False):
     """y = normalize(z); h = relu(y) if relu (reference layers/sage.py:131-132,
@@ -1000,12 +1031,14 @@ def logit_layer_bwd_dw(dz, seg_ptr, src, m, reduce, w_l, w_r, dh, agg, dw_l, h_r
 
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0.999, eps=1e-8,
-              weight_decay=0.0, grad_scale=1.0, step_out=None, zero_grad=False, done_event=None):
+              weight_decay=0.0, grad_scale=1.0, step_out=None, zero_grad=False, done_event=None, parts=None):
     """torch.optim.Adam step on flat fp32 buffers.  The step count is read from step_dev
     (int64[1]) and count+1 written to step_out (default: step_dev itself, which costs a second
     tiny kernel).  zero_grad=True clears grad after use.  done_event: a torch.cuda.Event that has
     been recorded at least once (its handle exists) — attached to the launch as its completion
-    event instead of a record() behind it (sage_adam_step_signal)."""
+    event instead of a record() behind it (sage_adam_step_signal).  parts = (ws, part_stride,
+    nparts, region_off, region_len): the gradient of that region of the flat buffer is the sum of
+    nparts partial buffers (linear_dweight2_parts; sage_adam_step_parts)."""
     lib = _lib.load()
     n = param.numel()
     for t, name in ((param, "param"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
@@ -1018,13 +1051,23 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step_dev, lr, beta1=0.9, beta2=0
             _count(step_dev, "step_dev"),
             _count(step_dev if step_out is None else step_out, "step_out"),
             1 if zero_grad else 0)
-    if done_event is None:
+    handle = None
+    if done_event is not None:
+        handle = done_event.cuda_event
+        if not handle:
+            raise RuntimeError("adam_step: done_event has no handle yet (record it once first)")
+    if parts is not None:
+        ws, stride, nparts, off, length = parts
+        if ws.dtype != torch.float32 or not ws.is_contiguous() or ws.numel() < (nparts - 1) * stride + length \
+                or step_out is None:
+            raise RuntimeError("adam_step: bad partial-sum buffers (and step_out must be a word of its own)")
+        _lib.check(lib.sage_adam_step_parts(*args, _p(ws, torch.float32, "ws"), int(stride), int(nparts), int(off),
+                                            int(length), ctypes.c_void_p(handle) if handle else None, _stream()),
+                   "sage_adam_step_parts")
+    elif handle is None:
         _lib.check(lib.sage_adam_step(*args, _stream()), "sage_adam_step")
-        return
-    handle = done_event.cuda_event
-    if not handle:
-        raise RuntimeError("adam_step: done_event has no handle yet (record it once first)")
-    _lib.check(lib.sage_adam_step_signal(*args, ctypes.c_void_p(handle), _stream()), "sage_adam_step_signal")
+    else:
+        _lib.check(lib.sage_adam_step_signal(*args, ctypes.c_void_p(handle), _stream()), "sage_adam_step_signal")
 
 
 # ------------------------------------------------------------------------------- a-7

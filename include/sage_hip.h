@@ -335,6 +335,17 @@ int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1, s
                          const float* a2, sage_i64 ld_a2, const sage_i64* rows2, int k2,
                          float* dw2, sage_i64 ld_dw2, sage_i64 m, const sage_i64* m_dev, int n,
                          void* stream);
+/* sage_linear_dweight2 WITHOUT the atomics where it can: when the launch takes the sliced bf16x3
+ * path (n >= 256, m >= 2048, aligned operands) with 2 .. max_parts slices, slice z STORES its
+ * partial sums at dw1 + z * part_stride / dw2 + z * part_stride and *parts = the number of
+ * slices (host int, a function of the shapes only): the true gradient is the sum over z, which
+ * sage_adam_step_parts forms while it reads it.  Otherwise *parts = 1 and the sums are ADDED into
+ * dw1 / dw2 as by sage_linear_dweight2.  No counterpart in the reference. */
+int sage_linear_dweight2_parts(const float* dout, sage_i64 ld_dout, const float* a1, sage_i64 ld_a1,
+                               const sage_i64* rows1, int k1, float* dw1, sage_i64 ld_dw1,
+                               const float* a2, sage_i64 ld_a2, const sage_i64* rows2, int k2,
+                               float* dw2, sage_i64 ld_dw2, sage_i64 m, const sage_i64* m_dev, int n,
+                               sage_i64 part_stride, int max_parts, int* parts, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * (a-7) LSTM aggregator (layers/sage.py:67-69, :147-193): per target, the first n_in
@@ -638,6 +649,17 @@ int sage_adam_step_signal(float* param, float* grad, float* exp_avg, float* exp_
                    sage_i64 numel, float lr, float beta1, float beta2, float eps,
                    float weight_decay, float grad_scale, const sage_i64* step_in,
                    sage_i64* step_out, int zero_grad, void* done_event, void* stream);
+/* Adam where the gradient of flat elements [region_off, region_off + region_len) is the sum of
+ * `parts` partial buffers ws + s * part_stride (sage_linear_dweight2_parts; parts = 1: the
+ * gradient itself, kept outside `grad` — its producer ADDS into it, so it is cleared after use
+ * if zero_grad); grad is not touched for those elements.  step_in and
+ * step_out must be different words.  done_event: NULL or as in sage_adam_step_signal. */
+int sage_adam_step_parts(float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                         sage_i64 numel, float lr, float beta1, float beta2, float eps,
+                         float weight_decay, float grad_scale, const sage_i64* step_in,
+                         sage_i64* step_out, int zero_grad, float* ws, sage_i64 part_stride,
+                         int parts, sage_i64 region_off, sage_i64 region_len, void* done_event,
+                         void* stream);
 
 #ifdef __cplusplus
 }

@@ -424,6 +424,41 @@ def test_reddit_shape_lstm_engine_step_matches_module_path(reddit, dev, monkeypa
             q.data.copy_(p.data)
 
 
+def test_reddit_shape_weight_gradient_slices_match_atomics(reddit, dev):
+    """BASELINE.json configs[2], one GPU: the engine's default keeps the layer-0 weight gradients as
+    stored split-K slices that Adam sums (sage_linear_dweight2_parts / sage_adam_step_parts) — against
+    the engine that adds them into the flat gradient with fp32 atomics (keep_grads=True), whose
+    gradients the other tests hold to the oracle: same losses, same weights after every step (to
+    summation order), pipelined steps and the serial call; the sliced path is really taken."""
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    data, graph = reddit
+    torch.manual_seed(3)
+    model_a = GraphSAGE(602, 256, "mean", 2, 41).to(dev)
+    model_b = copy.deepcopy(model_a)
+    mk = lambda m, keep: SageTrainEngine(m, NeighborSampler.from_graph(graph, [25, 10], seed=0), graph.features(data),
+                                         graph.labels(data), B, lr=1e-3, keep_grads=keep)
+    atom, sliced = mk(model_a, True), mk(model_b, False)
+    assert atom.dw_parts is None and sliced.dw_parts is not None
+    pool = torch.randperm(data.num_nodes, generator=torch.Generator().manual_seed(5))[:6 * B].to(dev)
+    for s in range(6):
+        seeds = pool[s * B:(s + 1) * B]
+        la = atom.step(seeds, counter=40 + s).clone()
+        atom.grad.zero_()                      # (keep_grads leaves the flat gradient to the caller)
+        lb = sliced.step(seeds, counter=40 + s).clone()
+        torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
+        assert sliced.dw_parts['n'] >= 16                                   # 25 slices at this shape
+        w0 = sliced.dw_parts
+        assert float(sliced.grad[w0['off']:w0['off'] + w0['len']].abs().max()) == 0.0      # nothing lands in the flat gradient
+        for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+            off = (pb.data - pa.data).abs() > 1e-6 + 1e-4 * pa.data.abs()
+            assert int(off.sum()) <= 0.001 * off.numel(), (s, int(off.sum()))
+            pa.data.copy_(pb.data)         # (Adam's first steps amplify last-bit differences of tiny gradients)
+        atom.exp_avg.copy_(sliced.exp_avg)
+        atom.exp_avg_sq.copy_(sliced.exp_avg_sq)
+
+
 # ------------------------------------------------------------------------------------ configs[4]
 PN, PE, PF = 2_400_000, 62_000_000, 100
 
