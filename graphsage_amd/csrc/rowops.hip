@@ -604,6 +604,59 @@ adam_parts_kernel(float* __restrict__ param, float* __restrict__ grad, float* __
   param[i] = p - (lr / bc1) * (m1 / denom);
 }
 
+// ... four elements per thread (everything a multiple of 4 floats and 16-byte aligned): the 25
+// slices of the headline's layer-0 weight gradients are 31 MB of reads, 16 bytes per lane and load
+__global__ void __launch_bounds__(kBlock)
+adam_parts4_kernel(float4* __restrict__ param, float4* __restrict__ grad, float4* __restrict__ exp_avg,
+                   float4* __restrict__ exp_avg_sq, int64_t numel4, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, float grad_scale, const int64_t* __restrict__ step_in,
+                   int64_t* __restrict__ step_out, int zero_grad, float4* __restrict__ ws, int64_t stride4,
+                   int parts, int64_t off4, int64_t len4) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t step = *step_in;
+  if (i == 0 && step_out != nullptr) *step_out = step + 1;
+  if (i >= numel4) return;
+  float4 g4;
+  const int64_t r = i - off4;
+  if (r >= 0 && r < len4) {
+    float4* wp = ws + r;
+    g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto add = [&](const float4& a) { g4.x += a.x; g4.y += a.y; g4.z += a.z; g4.w += a.w; };
+    int sidx = 0;
+    for (; sidx + 4 <= parts; sidx += 4) {      // four slices in flight
+      const float4 a0 = wp[(sidx + 0) * stride4], a1 = wp[(sidx + 1) * stride4], a2 = wp[(sidx + 2) * stride4],
+                   a3 = wp[(sidx + 3) * stride4];
+      add(a0); add(a1); add(a2); add(a3);
+    }
+    for (; sidx < parts; ++sidx) add(wp[sidx * stride4]);
+    if (parts == 1 && zero_grad) wp[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    g4 = grad[i];
+    if (zero_grad) grad[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float t = static_cast<float>(step + 1);
+  const float bc1 = 1.f - powf(beta1, t);
+  const float bc2 = 1.f - powf(beta2, t);
+  const float4 p4 = param[i], m4 = exp_avg[i], v4 = exp_avg_sq[i];
+  // (per element the arithmetic of adam_kernel, operation for operation)
+  auto one = [&](float gi, float p, float m0, float v0, float& po, float& mo, float& vo) {
+    float g = gi * grad_scale;
+    if (weight_decay != 0.f) g += weight_decay * p;
+    mo = beta1 * m0 + (1.f - beta1) * g;
+    vo = beta2 * v0 + (1.f - beta2) * g * g;
+    const float denom = sqrtf(vo) / sqrtf(bc2) + eps;
+    po = p - (lr / bc1) * (mo / denom);
+  };
+  float4 po, mo, vo;
+  one(g4.x, p4.x, m4.x, v4.x, po.x, mo.x, vo.x);
+  one(g4.y, p4.y, m4.y, v4.y, po.y, mo.y, vo.y);
+  one(g4.z, p4.z, m4.z, v4.z, po.z, mo.z, vo.z);
+  one(g4.w, p4.w, m4.w, v4.w, po.w, mo.w, vo.w);
+  exp_avg[i] = mo;
+  exp_avg_sq[i] = vo;
+  param[i] = po;
+}
+
 // The same update, four elements per thread with 16-byte accesses (numel a multiple of 4, all
 // four buffers 16-byte aligned: the engine's flat buffers are): the lstm model's 45 M parameters
 // are eight streams of 180 MB per step — 479 us one float at a time.  Per element the arithmetic
@@ -907,10 +960,21 @@ extern "C" int sage_adam_step_parts(float* param, float* grad, float* exp_avg, f
   SAGE_REQUIRE(ws && parts >= 1 && region_off >= 0 && region_len > 0 && region_off + region_len <= numel &&
                    part_stride >= region_len,
                SAGE_EINVAL, "sage_adam_step_parts: bad partial-sum region");
-  hipExtLaunchKernelGGL(adam_parts_kernel, dim3(static_cast<unsigned>(cdiv(numel, kBlock))), dim3(kBlock), 0, stream,
-                        nullptr, static_cast<hipEvent_t>(done_event), 0, param, grad, exp_avg, exp_avg_sq, numel, lr, beta1,
-                        beta2, eps, weight_decay, grad_scale, step_in, step_out, zero_grad, ws, part_stride, parts,
-                        region_off, region_len);
+  auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (numel % 4 == 0 && part_stride % 4 == 0 && region_off % 4 == 0 && region_len % 4 == 0 && a16(param) && a16(grad) &&
+      a16(exp_avg) && a16(exp_avg_sq) && a16(ws)) {
+    hipExtLaunchKernelGGL(adam_parts4_kernel, dim3(static_cast<unsigned>(cdiv(numel / 4, kBlock))), dim3(kBlock), 0, stream,
+                          nullptr, static_cast<hipEvent_t>(done_event), 0, reinterpret_cast<float4*>(param),
+                          reinterpret_cast<float4*>(grad), reinterpret_cast<float4*>(exp_avg),
+                          reinterpret_cast<float4*>(exp_avg_sq), numel / 4, lr, beta1, beta2, eps, weight_decay, grad_scale,
+                          step_in, step_out, zero_grad, reinterpret_cast<float4*>(ws), part_stride / 4, parts,
+                          region_off / 4, region_len / 4);
+  } else {
+    hipExtLaunchKernelGGL(adam_parts_kernel, dim3(static_cast<unsigned>(cdiv(numel, kBlock))), dim3(kBlock), 0, stream,
+                          nullptr, static_cast<hipEvent_t>(done_event), 0, param, grad, exp_avg, exp_avg_sq, numel, lr,
+                          beta1, beta2, eps, weight_decay, grad_scale, step_in, step_out, zero_grad, ws, part_stride, parts,
+                          region_off, region_len);
+  }
   SAGE_CHECK_LAUNCH("adam_parts_kernel");
   return SAGE_OK;
 }

@@ -6,7 +6,7 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name'] or 'adam4_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'adam' in r['Kernel_Name'] and 'sage::' in r['Kernel_Name']]      # adam_kernel, adam4_kernel, adam_parts*_kernel
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 a, b = idx[-k], idx[-k + 1]
 t0 = int(rows[a + 1]['Start_Timestamp'])
