@@ -13,11 +13,17 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
     batch's node vector — batch.x is never materialised;
   * all gradients live in one flat buffer (one all-reduce under data parallelism, one Adam
     launch);
-  * the class-logit layer of the supervised mean / sum step is two launches
-    (sage_logit_layer_fwd / _bwd: reduce, both weight products, normalise, cross entropy and
-    their backward for the B seed rows), and the hidden layer below it is never normalised as
-    a whole: the forward kernel normalises the rows it gathers, the backward works from the
-    pre-activation rows (sage_l2norm_relu_bwd_z);
+  * the class-logit layer of the supervised mean / sum step is ONE launch
+    (sage_logit_layer_fwd_bwd: reduce, both weight products, normalise, cross entropy and, in
+    the same wave, the seed's input gradient — rows of the hidden gradient that only one seed
+    writes are stored, not added, sage_count_row_writers), its weight gradients and the loss
+    mean ride in front of the next launch's grid (sage_l2norm_relu_bwd_z_dw), and the hidden
+    layer below it is never normalised as a whole: the forward kernel normalises the rows it
+    gathers, the backward works from the pre-activation rows;
+  * on one GPU the layer-0 weight gradients never pass through atomics: the split-K slices are
+    stored and Adam sums them as it reads them (sage_linear_dweight2_parts /
+    sage_adam_step_parts); the Adam launch carries the end-of-step event as its completion
+    signal (sage_adam_step_signal);
   * the pooling aggregators keep P = relu(pool(x)) per SOURCE row of a layer in a static buffer
     and route d agg back through the reduce and the ReLU in one edge pass
     (sage_pool_linear_fwd / sage_pool_max_bwd / sage_pool_mean_bwd); their large weight
