@@ -1847,6 +1847,14 @@ extern "C" int sage_linear_dweight2_parts(const float* dout, sage_i64 ld_dout, c
                                           int max_parts, int* parts, void* stream_) {
   SAGE_REQUIRE(parts != nullptr && max_parts >= 1 && part_stride > 0, SAGE_EINVAL,
                "sage_linear_dweight2_parts: parts is NULL, max_parts < 1 or part_stride <= 0");
-  return linear_dweight2_impl(dout, ld_dout, a1, ld_a1, rows1, k1, dw1, ld_dw1, a2, ld_a2, rows2, k2, dw2, ld_dw2, m, m_dev,
-                              n, part_stride, max_parts, parts, stream_);
+  // *parts on entry: 0, or what an earlier call with these shapes returned — a caller that replays
+  // recorded calls (and has told its consumer that number) learns here if the route has changed
+  // under it (SAGE_GEMM_X3 / SAGE_GEMM_BM are read at every call)
+  const int expected = *parts;
+  const int rc = linear_dweight2_impl(dout, ld_dout, a1, ld_a1, rows1, k1, dw1, ld_dw1, a2, ld_a2, rows2, k2, dw2, ld_dw2, m,
+                                      m_dev, n, part_stride, max_parts, parts, stream_);
+  if (rc != SAGE_OK) return rc;
+  SAGE_REQUIRE(expected == 0 || expected == *parts, SAGE_EINVAL,
+               "sage_linear_dweight2_parts: %d parts now, %d when the caller first asked", *parts, expected);
+  return SAGE_OK;
 }

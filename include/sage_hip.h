@@ -340,7 +340,9 @@ int sage_linear_dweight2(const float* dout, sage_i64 ld_dout, const float* a1, s
  * partial sums at dw1 + z * part_stride / dw2 + z * part_stride and *parts = the number of
  * slices (host int, a function of the shapes only): the true gradient is the sum over z, which
  * sage_adam_step_parts forms while it reads it.  Otherwise *parts = 1 and the sums are ADDED into
- * dw1 / dw2 as by sage_linear_dweight2.  No counterpart in the reference. */
+ * dw1 / dw2 as by sage_linear_dweight2.  *parts on entry: 0, or the number an earlier call
+ * returned — a different result is then an error (SAGE_EINVAL), for callers that replay recorded
+ * calls.  No counterpart in the reference. */
 int sage_linear_dweight2_parts(const float* dout, sage_i64 ld_dout, const float* a1, sage_i64 ld_a1,
                                const sage_i64* rows1, int k1, float* dw1, sage_i64 ld_dw1,
                                const float* a2, sage_i64 ld_a2, const sage_i64* rows2, int k2,

