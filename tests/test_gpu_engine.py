@@ -53,6 +53,43 @@ def test_engine_matches_module_path(dev, aggregator, monkeypatch):
     assert int(engine.step_dev) == 4
 
 
+@pytest.mark.parametrize("aggregator,keep", [("mean", True), ("mean", False), ("sum", False), ("max", False)])
+def test_three_layer_engine_matches_module_path(dev, aggregator, keep):
+    """Three SAGE layers (reference models/graphsage.py:44-49 with num_layers = 3): the class-logit
+    layer's one-launch forward + backward sits on layer 2, its riders on layer 1's pass, the stored
+    weight-gradient slices on layer 0 (keep=False) — losses and, with keep_grads, every gradient
+    against the module path; weights after Adam either way."""
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler, UniformLoader
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = planted_partition(2500, 40000, 40, 6, seed=6)
+    B, fan = 48, [5, 3, 2]
+    loader = UniformLoader(data, num_neighbors=fan, input_nodes=torch.arange(4 * B), batch_size=B, seed=5)
+    torch.manual_seed(4)
+    model_a = GraphSAGE(40, 32, aggregator, 3, 6).to(dev)
+    model_b = copy.deepcopy(model_a)
+    graph = device_graph(data)
+    engine = SageTrainEngine(model_b, NeighborSampler(data, fan, seed=5), graph.features(data), graph.labels(data), B,
+                             lr=1e-2, keep_grads=keep)
+    assert engine.logit_fwdbwd == (aggregator in ("mean", "sum")) and (engine.dw_parts is None) == keep
+    opt = torch.optim.Adam(model_a.parameters(), lr=1e-2)
+    for b, batch in enumerate(loader):
+        opt.zero_grad()
+        loss_a = F.cross_entropy(model_a.forward_batch(batch), batch.y[:B])
+        loss_a.backward()
+        opt.step()
+        loss_b = engine.step(torch.arange(b * B, (b + 1) * B, device=dev), counter=b)
+        torch.testing.assert_close(loss_b[0], loss_a.detach(), rtol=1e-5, atol=1e-6)
+        if keep:
+            for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+                torch.testing.assert_close(engine.gviews[pb], pa.grad, rtol=1e-3, atol=1e-6)
+            engine.grad.zero_()
+        for pa, pb in zip(model_a.parameters(), model_b.parameters()):
+            torch.testing.assert_close(pb.data, pa.data, rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("fanout,n_in,padsum", [([4, 2, 3], 6, True), ([6, 4], 4, False), ([3, 5], 4, False)])
 def test_lstm_engine_padded_slot_split(dev, fanout, n_in, padsum, monkeypatch):
     """lstm layer 0 on the engine: the rows behind the seeds contract their padded slots once
