@@ -26,6 +26,12 @@ src = torch.randint(0, nb, (13312 * deg,), device=dev)
 
 fwd = lambda: ops.linear_concat_fwd(agg, wl, table, wr, m=13312, m_dev=mdev, rows2=rows, out=out)
 dw = lambda: ops.linear_dweight2(dz, agg, dwl, table, dwr, m=13312, m_dev=mdev, rows2=rows)
+import ctypes
+_region = 2 * N * ld
+_ws = torch.zeros(32 * _region, device=dev)
+_v1, _v2 = _ws[:N * ld].view(N, ld)[:, :K], _ws[N * ld:_region].view(N, ld)[:, :K]
+_holder = ctypes.c_int(0)
+dwp = lambda: ops.linear_dweight2_parts(dz, agg, _v1, table, _v2, _region, 32, _holder, m=13312, m_dev=mdev, rows2=rows)
 gat = lambda: ops.gather_reduce_fwd(table, seg, src, 13312, 'mean', node_map=node, num_targets_dev=mdev,
                                     out=agg2, want_argmax=False)
 
@@ -38,7 +44,7 @@ def timeit(fn, n=20):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 
-for prio in (None, 'side_low', 'main_high'):
+for prio in (None,):
     if prio is None:
         main, side = torch.cuda.Stream(), torch.cuda.Stream()
     elif prio == 'side_low':
@@ -46,7 +52,7 @@ for prio in (None, 'side_low', 'main_high'):
     else:
         main, side = torch.cuda.Stream(priority=-1), torch.cuda.Stream(priority=0)
     print("priorities", prio, main.priority, side.priority)
-    for name, g in (("fwd", fwd), ("dweight2", dw)):
+    for name, g in (("fwd", fwd), ("dweight2", dw), ("dw slices", dwp)):
         with torch.cuda.stream(main):
             tg = timeit(g); tq = timeit(gat)
             def serial():
