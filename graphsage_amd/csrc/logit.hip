@@ -139,7 +139,10 @@ struct WeightStage {
 // are written to h_root for the root term's weight gradient.
 // BWD: the seed's backward in the same wave, behind its forward (dz never leaves the lanes, the
 // weights are staged once): dh[src[e]] += (dz . W_l) (/ deg), dh[t] += dz . W_r as in logit_bwd_body.
-template <int NV, bool FULL, bool PRE, bool BWD = false>      // FULL: h == 256 NV, no lane is ever out of the row
+// MAX: the neighbour reduce is the element-wise maximum (first edge on ties, 0 for an empty segment:
+// gather_reduce_fwd_kernel's rule), and the backward sends each column's gradient to the row that
+// supplied it — one add per column instead of one row per edge.
+template <int NV, bool FULL, bool PRE, bool BWD = false, bool MAX = false>      // FULL: h == 256 NV, no lane is ever out of the row
 __global__ void __launch_bounds__(kLogitBlock)
 logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
                  const int64_t* __restrict__ src, int64_t m, int h, int mean,
@@ -184,8 +187,13 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
 
   LOGIT_STAMP(0, 0);
   float4 acc[NV], root[NV];
+  int arg[MAX ? NV : 1][4];          // MAX: the edge (relative to s0) that supplied each maximum, -1 = none yet
 #pragma unroll
   for (int v = 0; v < NV; ++v) acc[v] = root[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int v = 0; v < (MAX ? NV : 1); ++v)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) arg[v][j] = -1;
   // requests in the order their results are needed; none waits for another except where noted
   const int64_t tc = live ? t : m - 1;                 // (dead waves of the last workgroup: clamped, results unused)
   const int64_t s0 = seg_ptr[tc];
@@ -266,10 +274,24 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
               if (in_row(v)) {
-                acc[v].x += x[r][v].x;
-                acc[v].y += x[r][v].y;
-                acc[v].z += x[r][v].z;
-                acc[v].w += x[r][v].w;
+                if constexpr (MAX) {
+                  const int e = static_cast<int>(base) + r0 + r;
+                  auto upd = [&](float& a, int& g, float val) {
+                    if (g < 0 || val > a) {
+                      a = val;
+                      g = e;
+                    }
+                  };
+                  upd(acc[v].x, arg[v][0], x[r][v].x);
+                  upd(acc[v].y, arg[v][1], x[r][v].y);
+                  upd(acc[v].z, arg[v][2], x[r][v].z);
+                  upd(acc[v].w, arg[v][3], x[r][v].w);
+                } else {
+                  acc[v].x += x[r][v].x;
+                  acc[v].y += x[r][v].y;
+                  acc[v].z += x[r][v].z;
+                  acc[v].w += x[r][v].w;
+                }
               }
             }
           }
@@ -389,7 +411,49 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
     dz[t * ld_dz + lane] = dzv;
   }
   LOGIT_STAMP(0, 6);
-  if constexpr (BWD) {
+  if constexpr (BWD && MAX) {
+    // in the forward's column layout (a lane holds columns 4 (lane + 64 v) .. + 3): the gradient of
+    // column f goes to the one row that supplied the maximum — h adds per seed, not h per edge
+    float4 da4[NV], dr4[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) da4[v] = dr4[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c0 = 0; c0 < n; c0 += 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j < n ? c0 + j : n - 1;
+        float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dzv), c));   // c is wave-uniform
+        if (c0 + j >= n) d = 0.f;
+        const float4* wl = reinterpret_cast<const float4*>(wlds + static_cast<int64_t>(c) * 2 * h);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const int col = in_row(v) ? lane + kWave * v : 0;
+          const float4 a = wl[col], b = wl[nq + col];
+          da4[v].x += d * a.x; da4[v].y += d * a.y; da4[v].z += d * a.z; da4[v].w += d * a.w;
+          dr4[v].x += d * b.x; dr4[v].y += d * b.y; dr4[v].z += d * b.z; dr4[v].w += d * b.w;
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (!in_row(v)) continue;
+      float* rootp = dh + t * ld_dh + 4 * (lane + kWave * v);
+      const float dr[4] = {dr4[v].x, dr4[v].y, dr4[v].z, dr4[v].w};
+      const float da[4] = {da4[v].x, da4[v].y, da4[v].z, da4[v].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (solo_root) rootp[j] = dr[j];      // (wave-uniform)
+        else atomicAdd(rootp + j, dr[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (arg[v][j] >= 0) {
+          const int64_t row = src[s0 + arg[v][j]];
+          atomicAdd(dh + row * ld_dh + 4 * (lane + kWave * v) + j, da[j]);
+        }
+      }
+    }
+    LOGIT_STAMP(0, 7);
+  } else if constexpr (BWD) {
     // (lane l owns columns l + 64 k here: every atomic wave-instruction adds 256 contiguous bytes)
     constexpr int NC = 4 * NV;
     float da[NC], dr[NC];
@@ -588,8 +652,10 @@ logit_bwd_dw_kernel(const float* __restrict__ dz, int64_t ld_dz, const int64_t* 
 inline bool vec16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int check_common(const char* who, sage_i64 m, int h, int n, int reduce, const float* w_l, sage_i64 ld_wl,
-                 const float* w_r, sage_i64 ld_wr, size_t* lds_bytes) {
-  SAGE_REQUIRE(reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM, SAGE_EINVAL, "%s: reduce must be mean or sum", who);
+                 const float* w_r, sage_i64 ld_wr, size_t* lds_bytes, bool max_ok = false) {
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM || (max_ok && reduce == SAGE_REDUCE_MAX), SAGE_EINVAL,
+               "%s: reduce must be mean or sum%s", who,
+               max_ok ? " or max" : " (max: the one-launch forward + backward, sage_logit_layer_fwd_bwd, or the forward-only call)");
   SAGE_REQUIRE(m > 0 && n > 0 && h > 0, SAGE_EINVAL, "%s: bad shape (m=%lld h=%d n=%d)", who, (long long)m, h, n);
   SAGE_REQUIRE(n <= kWave && h % 4 == 0 && h <= 1024, SAGE_ELIMIT,
                "%s: needs at most 64 outputs and a width that is a multiple of 4, at most 1024 (n=%d h=%d)", who, n, h);
@@ -640,17 +706,23 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
                      float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz, float* row_loss, float* h_root,
                      sage_i64 ld_h_root, sage_i64* pred, float* dh, sage_i64 ld_dh, const int* writers, hipStream_t stream) {
   size_t lds = 0;
-  const int rc = check_common(who, m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds);
+  // (max: its backward needs the arg-max of every column, which only lives in the forward's registers)
+  const int rc = check_common(who, m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds, dz == nullptr || dh != nullptr);
   if (rc != SAGE_OK) return rc;
   const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
   const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
-#define SAGE_LOGIT_FWD_P(NV, FULL, PRE, BWD)                                                                    \
+#define SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, MAX)                                                               \
   do {                                                                                                      \
-    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE, BWD>, lds, who);                              \
+    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE, BWD, MAX>, lds, who);                         \
     if (rc2 != SAGE_OK) return rc2;                                                                         \
-    logit_fwd_kernel<NV, FULL, PRE, BWD><<<grid, kLogitBlock, lds, stream>>>(                               \
+    logit_fwd_kernel<NV, FULL, PRE, BWD, MAX><<<grid, kLogitBlock, lds, stream>>>(                          \
         h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, \
         ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, pred, dh, ld_dh, writers);                  \
+  } while (0)
+#define SAGE_LOGIT_FWD_P(NV, FULL, PRE, BWD)                                                                    \
+  do {                                                                                                      \
+    if (reduce == SAGE_REDUCE_MAX) SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, true);                              \
+    else SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, false);                                                       \
   } while (0)
 #define SAGE_LOGIT_FWD(NV, FULL)                                                                                \
   do {                                                                                                      \
@@ -671,6 +743,7 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
   else SAGE_LOGIT_FWD(4, false);
 #undef SAGE_LOGIT_FWD
 #undef SAGE_LOGIT_FWD_P
+#undef SAGE_LOGIT_FWD_Q
   SAGE_CHECK_LAUNCH("logit_fwd_kernel");
   return SAGE_OK;
 }

@@ -191,9 +191,14 @@ class SageTrainEngine:
             if unsup is True:
                 raise NotImplementedError("engine: the trainers' combined loss is implemented for single-label targets")
         # SAGE_NO_FUSED_LOGIT=1 keeps the separate kernels (the A/B switch of scratch/hb.sh)
+        # (max: only in the one-launch forward + backward form — the arg-max of every column lives in
+        # the forward's registers — so not with any of the switches that take that form apart)
+        max_ok = not any(os.environ.get(k) for k in ('SAGE_NO_FUSED_LOGIT_DW', 'SAGE_NO_PRENORM', 'SAGE_NO_LOGIT_FWDBWD',
+                                                     'SAGE_NO_FUSED_LOGIT_MAX'))
         self.fused_logit = (not os.environ.get('SAGE_NO_FUSED_LOGIT') and not unsup and not self.pool
                             and not self.multilabel
-                            and self.root and self.reduce in ('mean', 'sum') and len(model.layers) >= 2
+                            and self.root and (self.reduce in ('mean', 'sum') or (self.reduce == 'max' and max_ok))
+                            and len(model.layers) >= 2
                             and ops.logit_layer_supported(last_w.size(1), last_w.size(0)))
         # ... with the layer's weight gradients in the backward's launch (SAGE_NO_FUSED_LOGIT_DW=1: a launch of their own)
         self.fused_logit_dw = self.fused_logit and not os.environ.get('SAGE_NO_FUSED_LOGIT_DW')

@@ -580,7 +580,10 @@ int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_pt
  * its backward right behind its forward (a seed's input gradient needs nothing but its own dz;
  * the weights are staged in LDS once).  Arguments as sage_logit_layer_fwd + dh; dz, agg, h_root
  * and row_loss are still written for the weight gradients and the loss mean, which
- * sage_l2norm_relu_bwd_z_dw (or sage_linear_dweight2 + a mean) supplies. */
+ * sage_l2norm_relu_bwd_z_dw (or sage_linear_dweight2 + a mean) supplies.  This entry (and
+ * sage_logit_layer_infer) also takes reduce = SAGE_REDUCE_MAX (layers/sage.py:195-199, scatter max):
+ * element-wise maximum, first edge on ties, 0 for an empty segment; the backward sends every
+ * column's gradient to the row that supplied the maximum (the arg-max never leaves the wave). */
 int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
                              sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
                              const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,

@@ -704,6 +704,76 @@ def test_logit_layer_fused_matches_separate_kernels(dev, reduce, h, n):
             torch.testing.assert_close((gbuf - g0)[n:, :h].double(), wr64.grad, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("h,n,pre", [(256, 41, True), (64, 7, False), (512, 40, True), (36, 5, True), (1024, 10, False)])
+def test_logit_layer_max_reduce_matches_torch(dev, h, n, pre):
+    """reduce = max in the class-logit layer's one-launch forward + backward and in the forward-only
+    call (reference layers/sage.py:195-199: scatter max over the gathered rows; 0 for a target without
+    neighbours) — loss, d z, kept aggregate, input gradient and arg-max class against torch autograd
+    in float64 on ragged segments (empty, longer than a wave), with and without the rows' own
+    relu(normalize(.)) on the way in; the separate-backward entry refuses max."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(31 + h)
+    m, n_src = 77, 400
+    ldh = (h + 15) // 16 * 16
+    z = torch.randn(n_src, ldh, generator=g, device=dev)[:, :h]
+    deg = torch.randint(0, 30, (m,), generator=g, device=dev)
+    deg[3], deg[5] = 0, 70
+    seg_ptr = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    seg_ptr[1:] = deg.cumsum(0)
+    src = torch.randint(0, n_src, (int(seg_ptr[-1]),), generator=g, device=dev)
+    wbuf = torch.randn(2 * n, ldh, generator=g, device=dev) * 0.2
+    w_l, w_r = wbuf[:n, :h], wbuf[n:, :h]
+    labels = torch.randint(0, n, (m,), generator=g, device=dev)
+    agg = torch.zeros(m, ldh, device=dev)[:, :h]
+    y = torch.zeros(m, 64, device=dev)[:, :n]
+    dz = torch.zeros(m, 64, device=dev)[:, :n]
+    inv, rl = torch.zeros(m, device=dev), torch.zeros(m, device=dev)
+    h_root = torch.zeros(m, ldh, device=dev)[:, :h] if pre else None
+    dh = torch.zeros(n_src, ldh, device=dev)[:, :h]
+    writers = ops.count_row_writers(seg_ptr, src, m, torch.zeros(n_src, dtype=torch.int32, device=dev))
+    ops.logit_layer_fwd(z, seg_ptr, src, m, "max", w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=h_root, dh=dh,
+                        writers=writers)
+    # torch, float64
+    zr = z.double().clone().requires_grad_(True)
+    rows = F.relu(F.normalize(zr, dim=-1)) if pre else zr
+    a_ref = torch.zeros(m, h, dtype=torch.float64, device=dev)
+    for t in range(m):
+        s0, s1 = int(seg_ptr[t]), int(seg_ptr[t + 1])
+        if s1 > s0:
+            a_ref[t] = rows[src[s0:s1]].max(0).values
+    # (differentiable version of the same)
+    a_list = [rows[src[int(seg_ptr[t]):int(seg_ptr[t + 1])]].max(0).values if int(deg[t]) > 0
+              else torch.zeros(h, dtype=torch.float64, device=dev) for t in range(m)]
+    a_t = torch.stack(a_list)
+    zz = a_t @ w_l.double().t() + rows[:m] @ w_r.double().t()
+    yy = F.normalize(zz, dim=-1)
+    loss = F.cross_entropy(yy, labels)
+    loss.backward()
+    torch.testing.assert_close(agg.double(), a_t.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y.double(), yy.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rl.double().mean(), loss.detach(), rtol=1e-5, atol=1e-6)
+    if pre:
+        # the kernel's dh is the gradient w.r.t. the ACTIVATIONS; take torch's the same way
+        rows2 = F.relu(F.normalize(z.double(), dim=-1)).detach().requires_grad_(True)
+        a2 = torch.stack([rows2[src[int(seg_ptr[t]):int(seg_ptr[t + 1])]].max(0).values if int(deg[t]) > 0
+                          else torch.zeros(h, dtype=torch.float64, device=dev) for t in range(m)])
+        F.cross_entropy(F.normalize(a2 @ w_l.double().t() + rows2[:m] @ w_r.double().t(), dim=-1), labels).backward()
+        want_dh = rows2.grad
+    else:
+        want_dh = zr.grad
+    torch.testing.assert_close(dh.double(), want_dh, rtol=1e-4, atol=1e-6)
+    # forward only: the same logits and their arg-max
+    y2 = torch.zeros_like(y)
+    pred = torch.zeros(m, dtype=torch.int64, device=dev)
+    ops.logit_layer_infer(z, seg_ptr, src, m, "max", w_l, w_r, y=y2, pred=pred, pre_activation=pre)
+    torch.testing.assert_close(y2, y, rtol=1e-6, atol=1e-7)
+    assert torch.equal(pred, y2.argmax(dim=1))
+    with pytest.raises(RuntimeError, match="mean or sum"):
+        ops.logit_layer_bwd(dz, seg_ptr, src, m, "max", w_l, w_r, torch.zeros_like(dh))
+    with pytest.raises(RuntimeError, match="mean or sum"):      # forward with d z but nowhere to send the input gradient
+        ops.logit_layer_fwd(z, seg_ptr, src, m, "max", w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=h_root)
+
+
 @pytest.mark.parametrize("reduce,h,n", [("mean", 256, 41), ("sum", 64, 7), ("mean", 512, 40), ("mean", 36, 5),
                                         ("mean", 1024, 10)])
 def test_logit_layer_on_preactivation_rows(dev, reduce, h, n):
