@@ -142,7 +142,10 @@ struct WeightStage {
 // MAX: the neighbour reduce is the element-wise maximum (first edge on ties, 0 for an empty segment:
 // gather_reduce_fwd_kernel's rule), and the backward sends each column's gradient to the row that
 // supplied it — one add per column instead of one row per edge.
-template <int NV, bool FULL, bool PRE, bool BWD = false, bool MAX = false>      // FULL: h == 256 NV, no lane is ever out of the row
+// RED = 2 (gcn, layers/sage.py:114-117): the neighbour rows and ONE self-loop averaged, for targets
+// that have neighbours at all; no root weight — z = agg . w_l^T, w_r is not read for the products
+// — and the backward hands the target's own row the same share as every neighbour.
+template <int NV, bool FULL, bool PRE, bool BWD = false, int RED = 0>      // FULL: h == 256 NV, no lane is ever out of the row
 __global__ void __launch_bounds__(kLogitBlock)
 logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
                  const int64_t* __restrict__ src, int64_t m, int h, int mean,
@@ -157,6 +160,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   // take y and / or pred (the arg-max class of each seed row); every one of these tests is
   // wave-uniform.
   extern __shared__ __attribute__((aligned(16))) float wlds[];
+  constexpr bool MAX = RED == 1, GCN = RED == 2;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kLogitWaves + threadIdx.x / kWave;
   const bool live = t < m;      // wave-uniform; every wave takes part in the staging and the barrier
@@ -298,7 +302,16 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
         }
       }
     }
-    if (mean) {
+    if (GCN && len > 0) {      // the self-loop: the target's own (activated) row, added last and counted
+      const float cnt = static_cast<float>(len) + 1.f;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        acc[v].x = (acc[v].x + root[v].x) / cnt;
+        acc[v].y = (acc[v].y + root[v].y) / cnt;
+        acc[v].z = (acc[v].z + root[v].z) / cnt;
+        acc[v].w = (acc[v].w + root[v].w) / cnt;
+      }
+    } else if (!GCN && mean) {
       const float cnt = len > 0 ? static_cast<float>(len) : 1.f;
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
@@ -352,7 +365,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
           float qq = acc[v].x * a[j][v].x + acc[v].y * a[j][v].y + acc[v].z * a[j][v].z + acc[v].w * a[j][v].w;
-          qq += root[v].x * b[j][v].x + root[v].y * b[j][v].y + root[v].z * b[j][v].z + root[v].w * b[j][v].w;
+          if (!GCN) qq += root[v].x * b[j][v].x + root[v].y * b[j][v].y + root[v].z * b[j][v].z + root[v].w * b[j][v].w;
           q += in_row(v) ? qq : 0.f;
         }
         p[c0 + j] = c0 + j < n ? q : 0.f;
@@ -477,6 +490,12 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       }
     }
     float* rootp = dh + t * ld_dh;
+    if (GCN) {      // no root weight: the target's row takes the self-loop's share of d agg
+      if (len <= 0) return;
+      const float cnt = static_cast<float>(len) + 1.f;
+#pragma unroll
+      for (int k = 0; k < NC; ++k) dr[k] = da[k] = da[k] / cnt;
+    }
     if (solo_root) {      // (wave-uniform)
 #pragma unroll
       for (int k = 0; k < NC; ++k) {
@@ -489,7 +508,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       }
     }
     if (len <= 0) return;
-    if (mean) {
+    if (!GCN && mean) {
       const float cnt = static_cast<float>(len);
 #pragma unroll
       for (int k = 0; k < NC; ++k) da[k] /= cnt;
@@ -653,9 +672,11 @@ inline bool vec16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 
 int check_common(const char* who, sage_i64 m, int h, int n, int reduce, const float* w_l, sage_i64 ld_wl,
                  const float* w_r, sage_i64 ld_wr, size_t* lds_bytes, bool max_ok = false) {
-  SAGE_REQUIRE(reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM || (max_ok && reduce == SAGE_REDUCE_MAX), SAGE_EINVAL,
-               "%s: reduce must be mean or sum%s", who,
-               max_ok ? " or max" : " (max: the one-launch forward + backward, sage_logit_layer_fwd_bwd, or the forward-only call)");
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM ||
+                   (max_ok && (reduce == SAGE_REDUCE_MAX || reduce == SAGE_REDUCE_GCN)),
+               SAGE_EINVAL, "%s: reduce must be mean or sum%s", who,
+               max_ok ? ", max or gcn"
+                      : " (max / gcn: the one-launch forward + backward, sage_logit_layer_fwd_bwd, or the forward-only call)");
   SAGE_REQUIRE(m > 0 && n > 0 && h > 0, SAGE_EINVAL, "%s: bad shape (m=%lld h=%d n=%d)", who, (long long)m, h, n);
   SAGE_REQUIRE(n <= kWave && h % 4 == 0 && h <= 1024, SAGE_ELIMIT,
                "%s: needs at most 64 outputs and a width that is a multiple of 4, at most 1024 (n=%d h=%d)", who, n, h);
@@ -711,18 +732,19 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
   if (rc != SAGE_OK) return rc;
   const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
   const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
-#define SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, MAX)                                                               \
+#define SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, RED)                                                               \
   do {                                                                                                      \
-    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE, BWD, MAX>, lds, who);                         \
+    const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE, BWD, RED>, lds, who);                         \
     if (rc2 != SAGE_OK) return rc2;                                                                         \
-    logit_fwd_kernel<NV, FULL, PRE, BWD, MAX><<<grid, kLogitBlock, lds, stream>>>(                          \
+    logit_fwd_kernel<NV, FULL, PRE, BWD, RED><<<grid, kLogitBlock, lds, stream>>>(                          \
         h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, \
         ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, pred, dh, ld_dh, writers);                  \
   } while (0)
 #define SAGE_LOGIT_FWD_P(NV, FULL, PRE, BWD)                                                                    \
   do {                                                                                                      \
-    if (reduce == SAGE_REDUCE_MAX) SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, true);                              \
-    else SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, false);                                                       \
+    if (reduce == SAGE_REDUCE_MAX) SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, 1);                                 \
+    else if (reduce == SAGE_REDUCE_GCN) SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, 2);                            \
+    else SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, 0);                                                           \
   } while (0)
 #define SAGE_LOGIT_FWD(NV, FULL)                                                                                \
   do {                                                                                                      \

@@ -812,19 +812,20 @@ extern "C" int sage_l2norm_relu_bwd_z_dw(float* dh, sage_i64 ld_dh, float* z, sa
   SAGE_REQUIRE(n % 4 == 0 && n <= 1024 && ld_dh % 4 == 0 && ld_z % 4 == 0 && ld_dz % 4 == 0 && vec16(dh) && vec16(z) &&
                    vec16(dz),
                SAGE_ELIMIT, "sage_l2norm_relu_bwd_z_dw: needs 16-byte aligned rows of at most 1024 floats, a multiple of 4");
-  SAGE_REQUIRE(dz2 && agg2 && dw_l && h_root2 && dw_r && m2 > 0 && m2 < (1ll << 31) && n2 > 0 && n2 <= 64 && h2 > 0 &&
-                   ld_dz2 >= n2 && ld_agg2 >= h2 && ld_dwl >= h2 && ld_h_root2 >= h2 && ld_dwr >= h2,
+  const bool root = h_root2 != nullptr || dw_r != nullptr;      // (both NULL: a layer without a root weight — gcn)
+  SAGE_REQUIRE(dz2 && agg2 && dw_l && m2 > 0 && m2 < (1ll << 31) && n2 > 0 && n2 <= 64 && h2 > 0 && ld_dz2 >= n2 &&
+                   ld_agg2 >= h2 && ld_dwl >= h2 && (!root || (h_root2 && dw_r && ld_h_root2 >= h2 && ld_dwr >= h2)),
                SAGE_EINVAL, "sage_l2norm_relu_bwd_z_dw: bad weight-gradient operands (n2 <= 64)");
   SAGE_REQUIRE((loss == nullptr) == (row_loss == nullptr), SAGE_EINVAL,
                "sage_l2norm_relu_bwd_z_dw: pass row_loss and loss together (or neither)");
-  SAGE_REQUIRE(dz2 != dz && dz2 != dh && agg2 != dz && h_root2 != dz, SAGE_EINVAL,
+  SAGE_REQUIRE(dz2 != dz && dz2 != dh && agg2 != dz && (h_root2 == nullptr || h_root2 != dz), SAGE_EINVAL,
                "sage_l2norm_relu_bwd_z_dw: the weight-gradient operands must not be written by this pass");
   // the grid of sage_linear_dweight2's skinny pair: >= 32 rows of m2 per block, <= 16 slices
   NormDwRider d = {};
   d.dz2 = dz2;
   d.ld_dz2 = ld_dz2;
   d.p0 = {agg2, ld_agg2, nullptr, h2, dw_l, ld_dwl};
-  d.p1 = {h_root2, ld_h_root2, nullptr, h2, dw_r, ld_dwr};
+  d.p1 = {h_root2, ld_h_root2, nullptr, root ? h2 : 0, dw_r, ld_dwr};      // (k = 0: its workgroups return at once)
   int64_t sp = cdiv(m2, 32);
   if (sp > 16) sp = 16;
   if (sp < 1) sp = 1;

@@ -197,7 +197,7 @@ class SageTrainEngine:
                                                      'SAGE_NO_FUSED_LOGIT_MAX'))
         self.fused_logit = (not os.environ.get('SAGE_NO_FUSED_LOGIT') and not unsup and not self.pool
                             and not self.multilabel
-                            and self.root and (self.reduce in ('mean', 'sum') or (self.reduce == 'max' and max_ok))
+                            and ((self.root and self.reduce in ('mean', 'sum')) or (self.reduce in ('max', 'gcn') and max_ok))
                             and len(model.layers) >= 2
                             and ops.logit_layer_supported(last_w.size(1), last_w.size(0)))
         # ... with the layer's weight gradients in the backward's launch (SAGE_NO_FUSED_LOGIT_DW=1: a launch of their own)
@@ -765,8 +765,10 @@ class SageTrainEngine:
             # takes the ~11 rows per seed it reads through relu(normalize(.)) in registers and
             # leaves the seeds' own activations in h for the root term's weight gradient; the
             # backward works from z as well (sage_l2norm_relu_bwd_z) and hands it back zeroed
+            # (gcn: no root weight — the kernel takes w_l in its place and does not use it)
             lib.logit_layer_fwd(prev['z'] if self.prenorm else prev['h'], buf.seg_ptr, buf.src, B, self.reduce,
-                                layer.lin_l.weight, layer.lin_r.weight, self.labels, buf.node, last['agg'], last['y'],
+                                layer.lin_l.weight, layer.lin_r.weight if self.root else layer.lin_l.weight,
+                                self.labels, buf.node, last['agg'], last['y'],
                                 last['inv'], last['dz'], self.row_loss, h_root=prev['h'] if self.prenorm else None,
                                 dh=prev['dh'] if self.logit_fwdbwd else None,
                                 writers=self.writers[slot] if (self.logit_fwdbwd and self.writers is not None) else None)
@@ -829,7 +831,8 @@ class SageTrainEngine:
                     nxt, lay2 = act[i + 1], self.model.layers[i + 1]
                     lib.l2norm_relu_bwd_z_dw(a['dh'], a['z'], True, t_cap, t_dev, a['dz'], True,
                                              nxt['dz'], self.B, self.n_dev[slot][nxt['hop']], nxt['agg'],
-                                             self.gviews[lay2.lin_l.weight], a['h'], self.gviews[lay2.lin_r.weight],
+                                             self.gviews[lay2.lin_l.weight], a['h'] if self.root else None,
+                                             self.gviews[lay2.lin_r.weight] if self.root else None,
                                              self.row_loss, self.loss)
                 elif fused and self.prenorm and i == L - 2:
                     lib.l2norm_relu_bwd_z(a['dh'], a['z'], True, m=t_cap, m_dev=t_dev, dz=a['dz'], clear_dh=True)
@@ -1205,7 +1208,7 @@ class SageTrainEngine:
             # stream-K contraction of the next batch — or of the next TRAINING step)
             self._forward_layers(slot, 0, True, upto=self.L - 1)
             ops.logit_layer_infer(prev['h'], buf.seg_ptr, buf.src, B, self.reduce, layer.lin_l.weight,
-                                  layer.lin_r.weight, y=last['y'], pred=pred)
+                                  layer.lin_r.weight if self.root else layer.lin_l.weight, y=last['y'], pred=pred)
         self._taped_last_ptr('infer', slot, run, 15, pred)       # sage_logit_layer_infer(..., pred, stream)
 
     def _taped_last_ptr(self, what, slot, run, arg_index, out):

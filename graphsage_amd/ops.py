@@ -774,13 +774,15 @@ def l2norm_relu_bwd_z_dw(dh, z, relu, m, m_dev, dz, clear_dh, dz2, m2, m2_dev, a
     op, ld_dz = _mat(dz, "dz")
     d2p, ld_dz2 = _mat(dz2, "dz2")
     ap, ld_agg = _mat(agg2, "agg2")
-    rp, ld_hr = _mat(h_root2, "h_root2")
     glp, ld_gl = _mat(dw_l, "dw_l")
-    grp, ld_gr = _mat(dw_r, "dw_r")
     n2, h2 = dw_l.shape
+    if (h_root2 is None) != (dw_r is None):
+        raise RuntimeError("l2norm_relu_bwd_z_dw: h_root2 and dw_r go together (both None: no root weight)")
+    rp, ld_hr = (None, 0) if h_root2 is None else _mat(h_root2, "h_root2")
+    grp, ld_gr = (None, 0) if dw_r is None else _mat(dw_r, "dw_r")
     if dh.size(0) < m or dh.size(1) != n or dz.size(0) < m or dz.size(1) != n or z.size(0) < m \
             or dz2.size(0) < m2 or dz2.size(1) != n2 or agg2.size(0) < m2 or agg2.size(1) != h2 \
-            or h_root2.size(0) < m2 or h_root2.size(1) != h2 or tuple(dw_r.shape) != (n2, h2) \
+            or (h_root2 is not None and (h_root2.size(0) < m2 or h_root2.size(1) != h2 or tuple(dw_r.shape) != (n2, h2))) \
             or (row_loss is None) != (loss is None) or (row_loss is not None and row_loss.numel() < m2):
         raise RuntimeError("l2norm_relu_bwd_z_dw: bad buffers")
     rc = lib.sage_l2norm_relu_bwd_z_dw(dp, ld_dh, zp, ld_z, 1 if relu else 0, m, _count(m_dev, "m_dev"), n, op, ld_dz,

@@ -441,7 +441,8 @@ int sage_l2norm_relu_bwd_z(float* dh, sage_i64 ld_dh, float* z, sage_i64 ld_z, i
  *   (= sage_linear_dweight2 for n2 <= 64; rows limited by *m2_dev if given), and
  *   loss[0] = mean(row_loss[0:m2]) in a fixed order if row_loss / loss are given —
  * in workgroups of their own in front of the pass's: nothing they read is written by it (dz2,
- * agg2, h_root2 must not alias dz / dh). */
+ * agg2, h_root2 must not alias dz / dh).  h_root2 = dw_r = NULL: a layer without a root weight
+ * (gcn, layers/sage.py:62-65) — dw_l only. */
 int sage_l2norm_relu_bwd_z_dw(float* dh, sage_i64 ld_dh, float* z, sage_i64 ld_z, int relu_mask, sage_i64 m,
                               const sage_i64* m_dev, int n, float* dz, sage_i64 ld_dz, int clear_dh,
                               const float* dz2, sage_i64 ld_dz2, sage_i64 m2, const sage_i64* m2_dev, int n2,
@@ -583,7 +584,10 @@ int sage_logit_layer_bwd(const float* dz, sage_i64 ld_dz, const sage_i64* seg_pt
  * sage_l2norm_relu_bwd_z_dw (or sage_linear_dweight2 + a mean) supplies.  This entry (and
  * sage_logit_layer_infer) also takes reduce = SAGE_REDUCE_MAX (layers/sage.py:195-199, scatter max):
  * element-wise maximum, first edge on ties, 0 for an empty segment; the backward sends every
- * column's gradient to the row that supplied the maximum (the arg-max never leaves the wave). */
+ * column's gradient to the row that supplied the maximum (the arg-max never leaves the wave);
+ * and reduce = SAGE_REDUCE_GCN (layers/sage.py:114-117: neighbours and one self-loop averaged, no
+ * root weight): z = agg . w_l^T — w_r is ignored (pass w_l) — and the target's own row receives
+ * the self-loop's share of the gradient. */
 int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, const sage_i64* seg_ptr, const sage_i64* src,
                              sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl,
                              const float* w_r, sage_i64 ld_wr, int n, const sage_i64* labels,

@@ -10,7 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("aggregator", ["mean", "sum", "max", "max_pool", "mean_pool", "lstm"])
+@pytest.mark.parametrize("aggregator", ["mean", "sum", "max", "gcn", "max_pool", "mean_pool", "lstm"])
 def test_engine_matches_module_path(dev, aggregator, monkeypatch):
     from graphsage_amd import settings
     from graphsage_amd.datasets import planted_partition
@@ -53,7 +53,7 @@ def test_engine_matches_module_path(dev, aggregator, monkeypatch):
     assert int(engine.step_dev) == 4
 
 
-@pytest.mark.parametrize("aggregator,keep", [("mean", True), ("mean", False), ("sum", False), ("max", False)])
+@pytest.mark.parametrize("aggregator,keep", [("mean", True), ("mean", False), ("sum", False), ("max", False), ("gcn", True)])
 def test_three_layer_engine_matches_module_path(dev, aggregator, keep):
     """Three SAGE layers (reference models/graphsage.py:44-49 with num_layers = 3): the class-logit
     layer's one-launch forward + backward sits on layer 2, its riders on layer 1's pass, the stored

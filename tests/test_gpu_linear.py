@@ -704,11 +704,12 @@ def test_logit_layer_fused_matches_separate_kernels(dev, reduce, h, n):
             torch.testing.assert_close((gbuf - g0)[n:, :h].double(), wr64.grad, rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("reduce", ["max", "gcn"])
 @pytest.mark.parametrize("h,n,pre", [(256, 41, True), (64, 7, False), (512, 40, True), (36, 5, True), (1024, 10, False)])
-def test_logit_layer_max_reduce_matches_torch(dev, h, n, pre):
-    """reduce = max in the class-logit layer's one-launch forward + backward and in the forward-only
-    call (reference layers/sage.py:195-199: scatter max over the gathered rows; 0 for a target without
-    neighbours) — loss, d z, kept aggregate, input gradient and arg-max class against torch autograd
+def test_logit_layer_max_reduce_matches_torch(dev, h, n, pre, reduce):
+    """reduce = max / gcn in the class-logit layer's one-launch forward + backward and in the forward-only
+    call (reference layers/sage.py:195-199: scatter max over the gathered rows, 0 for a target without
+    neighbours; :114-117, :62-65: gcn = the neighbours and one self-loop averaged, no root weight) — loss, d z, kept aggregate, input gradient and arg-max class against torch autograd
     in float64 on ragged segments (empty, longer than a wave), with and without the rows' own
     relu(normalize(.)) on the way in; the separate-backward entry refuses max."""
     from graphsage_amd import ops
@@ -731,21 +732,30 @@ def test_logit_layer_max_reduce_matches_torch(dev, h, n, pre):
     h_root = torch.zeros(m, ldh, device=dev)[:, :h] if pre else None
     dh = torch.zeros(n_src, ldh, device=dev)[:, :h]
     writers = ops.count_row_writers(seg_ptr, src, m, torch.zeros(n_src, dtype=torch.int32, device=dev))
-    ops.logit_layer_fwd(z, seg_ptr, src, m, "max", w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=h_root, dh=dh,
+    if reduce == "gcn":
+        w_r = w_l                       # (no root weight: the kernel takes w_l in its place and ignores it)
+    ops.logit_layer_fwd(z, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=h_root, dh=dh,
                         writers=writers)
-    # torch, float64
+
+    def reduce_ref(rows):       # torch, float64, differentiable
+        out = []
+        for t in range(m):
+            s0, s1 = int(seg_ptr[t]), int(seg_ptr[t + 1])
+            if s1 == s0:
+                out.append(torch.zeros(h, dtype=torch.float64, device=dev))
+            elif reduce == "max":
+                out.append(rows[src[s0:s1]].max(0).values)
+            else:
+                out.append((rows[src[s0:s1]].sum(0) + rows[t]) / (s1 - s0 + 1))
+        return torch.stack(out)
+
+    def logits_ref(rows):
+        a = reduce_ref(rows)
+        zz_ = a @ w_l.double().t()
+        return a, (zz_ + rows[:m] @ w_r.double().t()) if reduce == "max" else zz_
     zr = z.double().clone().requires_grad_(True)
     rows = F.relu(F.normalize(zr, dim=-1)) if pre else zr
-    a_ref = torch.zeros(m, h, dtype=torch.float64, device=dev)
-    for t in range(m):
-        s0, s1 = int(seg_ptr[t]), int(seg_ptr[t + 1])
-        if s1 > s0:
-            a_ref[t] = rows[src[s0:s1]].max(0).values
-    # (differentiable version of the same)
-    a_list = [rows[src[int(seg_ptr[t]):int(seg_ptr[t + 1])]].max(0).values if int(deg[t]) > 0
-              else torch.zeros(h, dtype=torch.float64, device=dev) for t in range(m)]
-    a_t = torch.stack(a_list)
-    zz = a_t @ w_l.double().t() + rows[:m] @ w_r.double().t()
+    a_t, zz = logits_ref(rows)
     yy = F.normalize(zz, dim=-1)
     loss = F.cross_entropy(yy, labels)
     loss.backward()
@@ -755,9 +765,7 @@ def test_logit_layer_max_reduce_matches_torch(dev, h, n, pre):
     if pre:
         # the kernel's dh is the gradient w.r.t. the ACTIVATIONS; take torch's the same way
         rows2 = F.relu(F.normalize(z.double(), dim=-1)).detach().requires_grad_(True)
-        a2 = torch.stack([rows2[src[int(seg_ptr[t]):int(seg_ptr[t + 1])]].max(0).values if int(deg[t]) > 0
-                          else torch.zeros(h, dtype=torch.float64, device=dev) for t in range(m)])
-        F.cross_entropy(F.normalize(a2 @ w_l.double().t() + rows2[:m] @ w_r.double().t(), dim=-1), labels).backward()
+        F.cross_entropy(F.normalize(logits_ref(rows2)[1], dim=-1), labels).backward()
         want_dh = rows2.grad
     else:
         want_dh = zr.grad
@@ -765,13 +773,13 @@ def test_logit_layer_max_reduce_matches_torch(dev, h, n, pre):
     # forward only: the same logits and their arg-max
     y2 = torch.zeros_like(y)
     pred = torch.zeros(m, dtype=torch.int64, device=dev)
-    ops.logit_layer_infer(z, seg_ptr, src, m, "max", w_l, w_r, y=y2, pred=pred, pre_activation=pre)
+    ops.logit_layer_infer(z, seg_ptr, src, m, reduce, w_l, w_r, y=y2, pred=pred, pre_activation=pre)
     torch.testing.assert_close(y2, y, rtol=1e-6, atol=1e-7)
     assert torch.equal(pred, y2.argmax(dim=1))
     with pytest.raises(RuntimeError, match="mean or sum"):
-        ops.logit_layer_bwd(dz, seg_ptr, src, m, "max", w_l, w_r, torch.zeros_like(dh))
+        ops.logit_layer_bwd(dz, seg_ptr, src, m, reduce, w_l, w_r, torch.zeros_like(dh))
     with pytest.raises(RuntimeError, match="mean or sum"):      # forward with d z but nowhere to send the input gradient
-        ops.logit_layer_fwd(z, seg_ptr, src, m, "max", w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=h_root)
+        ops.logit_layer_fwd(z, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg, y, inv, dz, rl, h_root=h_root)
 
 
 @pytest.mark.parametrize("reduce,h,n", [("mean", 256, 41), ("sum", 64, 7), ("mean", 512, 40), ("mean", 36, 5),
