@@ -215,7 +215,7 @@ def test_pipelined_eager_matches_serial_steps(dev, overlap):
 
 
 @pytest.mark.parametrize("aggregator,overlap", [("mean", False), ("mean", True), ("sum", True), ("max", False),
-                                                ("max_pool", False), ("lstm", False)])
+                                                ("max", True), ("gcn", True), ("max_pool", False), ("lstm", False)])
 def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap, monkeypatch):
     """engine.evaluate() — the training pipeline run forward-only, one launch for the class-logit
     layer of the mean / sum step — predicts what GraphSAGE.inference + argmax predict
