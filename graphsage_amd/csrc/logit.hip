@@ -1,18 +1,21 @@
-// The class-logit layer of the supervised step in two launches (the last SAGE layer acts on the B
-// seed rows only: 512 targets, <= 25 sources each, C = 41 outputs — ~0.1 GFLOP and ~30 MB, a chain
-// of short dependent kernels when it is run as gather / GEMM / normalise+loss / d-input / scatter).
+// The class-logit layer of the supervised step (the last SAGE layer acts on the B seed rows only: 512
+// targets, <= 25 sources each, C = 41 outputs — ~0.1 GFLOP and ~30 MB, a chain of short dependent
+// kernels when it is run as gather / GEMM / normalise+loss / d-input / scatter).
 //
 //   forward  (one wave per seed, the [C, 2H] weights staged in LDS once per workgroup):
-//     agg = reduce_{e in seg(t)} h[src[e]]                          layers/sage.py:136-137, 209-210
+//     agg = reduce_{e in seg(t)} h[src[e]]   (sum / mean / max / gcn) layers/sage.py:136-137, 195-210
 //     z   = agg . W_l^T + h[t] . W_r^T                               layers/sage.py:124-129
 //     y   = z / max(|z|, eps);  CE(y, label);  dz = d loss / d z     layers/sage.py:131-132,
 //                                                                    fig2a/runners/graphsage_runners.py:43
-//   backward (one wave per seed, same staging):
+//   backward (the same wave, right behind its forward in the training step's launch — BWD; or a
+//   launch of its own, logit_bwd_kernel, mean / sum only):
 //     dh[src[e]] += (dz . W_l) / deg   for the segment's edges,   dh[t] += dz . W_r
-//     (what autograd derives for the two Linears and the scatter; lane l owns columns l + 64 k, so
-//     every atomic wave-instruction adds 256 contiguous bytes of one row)
-//     and loss = mean(row_loss), reduced by the first wave in a fixed order.
-// The weight gradients stay with sage_linear_dweight2 (they need agg, which the forward keeps).
+//     (what autograd derives for the two Linears and the scatter; rows that only one seed writes
+//     are stored instead of added; max sends each column to the row that supplied it)
+//   forward only (sage_logit_layer_infer): the arg-max class of every seed row.
+// The layer's weight gradients and the loss mean need every seed's dz: they ride as extra
+// workgroups in front of another launch's grid (skinny_dw.h; rowops.hip's normalise-backward pass
+// in the engine's step, or logit_bwd_dw_kernel below).
 #include "common.h"
 #include "skinny_dw.h"
 
