@@ -42,3 +42,16 @@ def load_layers(model, layers):
             if "pool_w" in p:
                 m.pool.weight.copy_(p["pool_w"])
                 m.pool.bias.copy_(p["pool_b"])
+
+
+def assert_trajectories_close(got, want, frac=0.02, worst=5e-4):
+    """Two engines that ran the same training steps: equal weights up to summation order.  fp32
+    atomics arrive in any order, and Adam turns a last-bit difference of a gradient near its eps
+    (1e-8: a parameter the batches barely touch) into a visible one — up to lr * |dg| / eps — which
+    then rides along for the rest of the trajectory.  So: all but a small fraction of the elements
+    agree to rtol 1e-4 / atol 1e-6, and none is further off than `worst` (a lost or doubled update
+    moves a weight by ~lr = 1e-2)."""
+    diff = (got - want).abs()
+    off = diff > 1e-6 + 1e-4 * want.abs()
+    assert int(off.sum()) <= frac * off.numel(), (int(off.sum()), off.numel())
+    assert float(diff.max()) <= worst, float(diff.max())

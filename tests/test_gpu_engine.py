@@ -7,6 +7,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests.helpers import assert_trajectories_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -161,7 +163,7 @@ def test_graph_replay_matches_eager_steps(dev, split, overlap=False):
         assert torch.equal(eager.buf.node[:n], graphed.buf.node[:n])
         assert torch.equal(eager.buf.src[:e], graphed.buf.src[:e])
         torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(graphed.flat, eager.flat, rtol=1e-4, atol=1e-6)
+        assert_trajectories_close(graphed.flat, eager.flat)
     assert int(graphed.state_sum[4]) == 0 and int(graphed.step_dev) == 8
     with pytest.raises(RuntimeError):
         graphed.step(pool[:B])
@@ -201,7 +203,7 @@ def test_pipelined_eager_matches_serial_steps(dev, overlap):
         assert torch.equal(serial.buf.node[:n], piped.buf.node[:n])
         assert torch.equal(serial.buf.src[:e], piped.buf.src[:e])
         torch.testing.assert_close(lb, la, rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(piped.flat, serial.flat, rtol=1e-4, atol=1e-6)
+        assert_trajectories_close(piped.flat, serial.flat)
     assert not piped.primed
     with pytest.raises(RuntimeError):
         piped.pipelined_step()
@@ -272,4 +274,4 @@ def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap, mo
             assert int(off.sum()) <= max(1, off.numel() // 1000), int(off.sum())
             ref_engine.flat.copy_(engine.flat)
         else:
-            torch.testing.assert_close(engine.flat, ref_engine.flat, rtol=1e-4, atol=1e-6)
+            assert_trajectories_close(engine.flat, ref_engine.flat)

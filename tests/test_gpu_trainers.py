@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import csc, sage_ref, sampler
-from tests.helpers import load_layers, make_layers
+from tests.helpers import assert_trajectories_close, load_layers, make_layers
 
 pytestmark = pytest.mark.gpu
 
@@ -105,7 +105,7 @@ def test_train_epoch_matches_step_loop(dev):
     mean_loss = ea.train_epoch(seeds, epoch=3)
     losses = [eb.step(seeds[b * B:(b + 1) * B], counter=batch_counter(3, 5, b, 0, 1)).clone() for b in range(5)]
     torch.testing.assert_close(mean_loss, torch.stack(losses).mean(0), rtol=1e-5, atol=1e-6)
-    torch.testing.assert_close(ea.flat, eb.flat, rtol=1e-4, atol=1e-6)
+    assert_trajectories_close(ea.flat, eb.flat)
     assert int(ea.step_dev) == 5
 
 
