@@ -135,6 +135,16 @@ __global__ void gather_rows_narrow_kernel(const uint32_t* __restrict__ table, in
 }
 
 // ---------------------------------------------------------------- gather + segment reduce
+// Where the max came from, per (target, column): `full` = the edge's index into src (or -1),
+// int64 [T, F] dense; `compact` = the edge's offset within the target's segment as one byte, 255
+// for "no gradient" (empty segment, offset above 254, or a maximum that is not positive — the
+// caller's rows are relu outputs, sage_pool_max_fwd), rows ld_compact bytes apart.
+struct ArgOut {
+  int64_t* full;
+  uint8_t* compact;
+  int64_t ld_compact;
+};
+
 // One wave per (target, feature slab).  A slab is 64*VEC*NV consecutive features.
 template <int VEC, int NV, int REDUCE>
 __global__ void __launch_bounds__(kBlock)
@@ -143,7 +153,7 @@ gather_reduce_fwd_kernel(const float* __restrict__ x, int64_t ld_x,
                          const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src,
                          int64_t num_targets, const int64_t* __restrict__ num_targets_dev,
                          int num_features, float* __restrict__ out, int64_t ld_out,
-                         int64_t* __restrict__ argmax) {
+                         ArgOut argmax) {
   using V = typename VecT<VEC>::type;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t nt = dev_count(num_targets_dev, num_targets);
@@ -241,11 +251,27 @@ gather_reduce_fwd_kernel(const float* __restrict__ x, int64_t ld_x,
       a[j] = (REDUCE == SAGE_REDUCE_MEAN || REDUCE == SAGE_REDUCE_GCN) ? acc[c][j] / cnt : acc[c][j];
     }
     *reinterpret_cast<V*>(out + t * ld_out + f) = arr_to_vec<VEC>(a);
-    if (REDUCE == SAGE_REDUCE_MAX && argmax != nullptr) {
+    if (REDUCE == SAGE_REDUCE_MAX && argmax.full != nullptr) {
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         if (f + j < num_features) {
-          argmax[t * static_cast<int64_t>(num_features) + f + j] = arg[c][j] < 0 ? -1 : s0 + arg[c][j];
+          argmax.full[t * static_cast<int64_t>(num_features) + f + j] = arg[c][j] < 0 ? -1 : s0 + arg[c][j];
+        }
+      }
+    }
+    if (REDUCE == SAGE_REDUCE_MAX && argmax.compact != nullptr) {
+      uint8_t* q = argmax.compact + t * argmax.ld_compact + f;
+      uint32_t b[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        b[j] = (arg[c][j] < 0 || arg[c][j] > 254 || !(a[j] > 0.f)) ? 255u : static_cast<uint32_t>(arg[c][j]);
+      }
+      if (VEC == 4 && f + 3 < num_features && (argmax.ld_compact & 3) == 0) {
+        *reinterpret_cast<uint32_t*>(q) = b[0] | (b[1] << 8) | (b[2 % VEC] << 16) | (b[3 % VEC] << 24);
+      } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (f + j < num_features) q[j] = static_cast<uint8_t>(b[j]);
         }
       }
     }
@@ -435,6 +461,126 @@ pool_mean_bwd_rows_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const
   }
 }
 
+// ---------------------------------------------------------------- the edge pass, pulled by source row
+// Second form (layer 0 of the engine's pooling step): the batch's edges listed per SOURCE row
+// (sage_pool_reverse_edges, which a caller can run as soon as the batch is sampled — the engine
+// does, on the sampler's stream, a step ahead), and one wave per source row that adds up what its
+// in-edges route to it and stores the row once: no atomics (a shared row's sparse adds cost one L2
+// operation per edge and 128-byte line whatever the number of live lanes: 60 of the max pass's 146
+// us), no zero-fill to rely on, P read once per row instead of once per edge (mean), 1 byte
+// instead of 8 + 4 per (target, column) to find the arg-max edge (max).
+// An entry of a row's list: target * 256 + min(offset of the edge in the target's segment, 255).
+__global__ void __launch_bounds__(kWave)
+pool_reverse_fill_kernel(const int64_t* __restrict__ seg_ptr, const int64_t* __restrict__ src, int64_t num_targets,
+                         const int64_t* __restrict__ num_targets_dev, int64_t num_sources,
+                         int* __restrict__ count, const int* __restrict__ rev_ptr, int* __restrict__ rev,
+                         int64_t rev_cap) {
+  const int64_t nt = dev_count(num_targets_dev, num_targets);
+  const int64_t t = blockIdx.x;
+  if (t >= nt) return;
+  const int64_t s0 = seg_ptr[t], s1 = seg_ptr[t + 1];
+  for (int64_t e = s0 + threadIdx.x; e < s1; e += kWave) {
+    const int64_t s = src[e];
+    if (s < 0 || s >= num_sources) continue;
+    // the counts of pool_indeg_kernel are handed back one by one: slot = what was left - 1
+    const int64_t pos = static_cast<int64_t>(rev_ptr[s]) + atomicSub(count + s, 1) - 1;
+    const int64_t off = e - s0;
+    if (pos >= 0 && pos < rev_cap) rev[pos] = static_cast<int>(t * 256 + (off < 255 ? off : 255));
+  }
+}
+
+constexpr int kPullCols = 4;    // consecutive columns per lane and pass (16-byte loads and stores)
+constexpr int kPullPasses = 3;  // passes of 64 lanes held in registers together: 768 columns
+
+template <bool MAX>
+__global__ void __launch_bounds__(kBlock)
+pool_pull_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const uint8_t* __restrict__ arg8,
+                 int64_t ld_arg8, const float* __restrict__ p, int64_t ld_p,
+                 const int64_t* __restrict__ seg_ptr, const int* __restrict__ rev_ptr,
+                 const int* __restrict__ rev, int64_t num_sources, const int64_t* __restrict__ num_sources_dev,
+                 int num_features, float* __restrict__ dpre, int64_t ld_dpre) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t ns = dev_count(num_sources_dev, num_sources);
+  const int64_t s = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
+  if (s >= ns) return;
+  const int b0 = rev_ptr[s], b1 = rev_ptr[s + 1];
+  for (int f0 = 0; f0 < num_features; f0 += kWave * kPullCols * kPullPasses) {
+    float acc[kPullPasses][kPullCols];
+    bool live[kPullPasses];
+#pragma unroll
+    for (int c = 0; c < kPullPasses; ++c) {
+      live[c] = f0 + (c * kWave + lane) * kPullCols < num_features;
+#pragma unroll
+      for (int j = 0; j < kPullCols; ++j) acc[c][j] = 0.f;
+    }
+    for (int base = b0; base < b1; base += kWave) {
+      const int chunk = (b1 - base) < kWave ? (b1 - base) : kWave;
+      int my_t = 0, my_j = 0;
+      float my_w = 0.f;
+      if (lane < chunk) {
+        const int ent = rev[base + lane];
+        my_t = ent >> 8;
+        my_j = ent & 255;
+        if (!MAX) my_w = 1.f / static_cast<float>(seg_ptr[my_t + 1] - seg_ptr[my_t]);
+      }
+      for (int r = 0; r < chunk; ++r) {
+        const int64_t tt = __builtin_amdgcn_readlane(my_t, r);
+        const uint32_t jj = static_cast<uint32_t>(__builtin_amdgcn_readlane(my_j, r));
+        const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), r));
+        const float* grow = dagg + tt * ld_dagg + f0 + lane * kPullCols;
+        float4 g[kPullPasses];
+        uint32_t a[kPullPasses];
+#pragma unroll
+        for (int c = 0; c < kPullPasses; ++c) {
+          if (live[c]) {
+            g[c] = *reinterpret_cast<const float4*>(grow + c * kWave * kPullCols);
+            if (MAX) a[c] = *reinterpret_cast<const uint32_t*>(arg8 + tt * ld_arg8 + f0 + (c * kWave + lane) * kPullCols);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < kPullPasses; ++c) {
+          if (!live[c]) continue;
+          if (MAX) {
+            acc[c][0] += (a[c] & 255u) == jj ? g[c].x : 0.f;
+            acc[c][1] += ((a[c] >> 8) & 255u) == jj ? g[c].y : 0.f;
+            acc[c][2] += ((a[c] >> 16) & 255u) == jj ? g[c].z : 0.f;
+            acc[c][3] += (a[c] >> 24) == jj ? g[c].w : 0.f;
+          } else {
+            acc[c][0] += w * g[c].x;
+            acc[c][1] += w * g[c].y;
+            acc[c][2] += w * g[c].z;
+            acc[c][3] += w * g[c].w;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kPullPasses; ++c) {
+      if (!live[c]) continue;
+      const int f = f0 + (c * kWave + lane) * kPullCols;
+      if (!MAX && b1 > b0) {   // the relu mask of the row itself
+        const float4 pv = *reinterpret_cast<const float4*>(p + s * ld_p + f);
+        if (!(pv.x > 0.f)) acc[c][0] = 0.f;
+        if (!(pv.y > 0.f)) acc[c][1] = 0.f;
+        if (!(pv.z > 0.f)) acc[c][2] = 0.f;
+        if (!(pv.w > 0.f)) acc[c][3] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < kPullCols; ++j) {
+        if (f + j >= num_features) acc[c][j] = 0.f;   // (the rows' padding up to a multiple of 4)
+      }
+      *reinterpret_cast<float4*>(dpre + s * ld_dpre + f) = make_float4(acc[c][0], acc[c][1], acc[c][2], acc[c][3]);
+    }
+  }
+}
+
+size_t scan32_temp_bytes(size_t n) {
+  size_t bytes = 0;
+  int* q = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, bytes, q, q, 0, n, rocprim::plus<int>(), nullptr);
+  return bytes;
+}
+
 // The pool bias gradient of the same step: every (t, f) lands in exactly one row of dpre, so the
 // column sums of dpre are the column sums of the masked dagg — 13k target rows instead of 81k
 // source rows (an empty segment has agg = 0, so agg > 0 alone says "routed and unmasked").
@@ -572,7 +718,7 @@ struct LaunchEvents {
 template <int VEC, int NV>
 int launch_fwd(const float* x, int64_t ld_x, const int64_t* node_map, const int64_t* seg_ptr,
                const int64_t* src, int64_t nt, const int64_t* nt_dev, int nf, int reduce,
-               float* out, int64_t ld_out, int64_t* argmax, const LaunchEvents& ev,
+               float* out, int64_t ld_out, ArgOut argmax, const LaunchEvents& ev,
                hipStream_t stream) {
   dim3 grid(static_cast<unsigned>(cdiv(nt, kWavesPerBlock)),
             static_cast<unsigned>(cdiv(nf, kWave * VEC * NV)));
@@ -606,7 +752,7 @@ int launch_fwd(const float* x, int64_t ld_x, const int64_t* node_map, const int6
 template <int VEC>
 int dispatch_fwd_nv(int nv, const float* x, int64_t ld_x, const int64_t* node_map,
                     const int64_t* seg_ptr, const int64_t* src, int64_t nt, const int64_t* nt_dev,
-                    int nf, int reduce, float* out, int64_t ld_out, int64_t* argmax,
+                    int nf, int reduce, float* out, int64_t ld_out, ArgOut argmax,
                     const LaunchEvents& ev, hipStream_t stream) {
   switch (nv) {
     case 1:
@@ -623,7 +769,7 @@ int dispatch_fwd_nv(int nv, const float* x, int64_t ld_x, const int64_t* node_ma
 int gather_reduce_fwd_impl(const float* x, sage_i64 ld_x, const sage_i64* node_map,
                            const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
                            const sage_i64* num_targets_dev, int num_features, int reduce,
-                           float* out, sage_i64 ld_out, sage_i64* argmax, const LaunchEvents& ev,
+                           float* out, sage_i64 ld_out, ArgOut argmax, const LaunchEvents& ev,
                            void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   SAGE_REQUIRE(reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX ||
@@ -658,7 +804,22 @@ extern "C" int sage_gather_reduce_fwd(const float* x, sage_i64 ld_x, const sage_
                                       int num_features, int reduce, float* out, sage_i64 ld_out,
                                       sage_i64* argmax, void* stream) {
   return gather_reduce_fwd_impl(x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
-                                num_features, reduce, out, ld_out, argmax,
+                                num_features, reduce, out, ld_out, ArgOut{argmax, nullptr, 0},
+                                LaunchEvents{nullptr, nullptr}, stream);
+}
+
+extern "C" int sage_pool_max_fwd(const float* p, sage_i64 ld_p, const sage_i64* seg_ptr, const sage_i64* src,
+                                 sage_i64 num_targets, const sage_i64* num_targets_dev, int num_features,
+                                 int max_segment, float* out, sage_i64 ld_out, unsigned char* arg8,
+                                 sage_i64 ld_arg8, void* stream) {
+  SAGE_REQUIRE(arg8 != nullptr && ld_arg8 >= num_features && reinterpret_cast<uintptr_t>(arg8) % 4 == 0,
+               SAGE_EINVAL, "sage_pool_max_fwd: arg8 NULL, rows shorter than num_features, or not 4-byte aligned");
+  SAGE_REQUIRE(max_segment >= 0 && max_segment <= 255, SAGE_EINVAL,
+               "sage_pool_max_fwd: segments of up to %d edges do not fit the one-byte offsets (255 at most); "
+               "use sage_gather_reduce_fwd with the int64 argmax",
+               max_segment);
+  return gather_reduce_fwd_impl(p, ld_p, nullptr, seg_ptr, src, num_targets, num_targets_dev, num_features,
+                                SAGE_REDUCE_MAX, out, ld_out, ArgOut{nullptr, arg8, ld_arg8},
                                 LaunchEvents{nullptr, nullptr}, stream);
 }
 
@@ -673,7 +834,7 @@ extern "C" int sage_gather_reduce_fwd_timed(const float* x, sage_i64 ld_x, const
   SAGE_REQUIRE(num_targets > 0, SAGE_EINVAL,
                "sage_gather_reduce_fwd_timed: nothing to launch (num_targets = 0), the events would stay unrecorded");
   return gather_reduce_fwd_impl(x, ld_x, node_map, seg_ptr, src, num_targets, num_targets_dev,
-                                num_features, reduce, out, ld_out, argmax,
+                                num_features, reduce, out, ld_out, ArgOut{argmax, nullptr, 0},
                                 LaunchEvents{static_cast<hipEvent_t>(start_event),
                                              static_cast<hipEvent_t>(stop_event)},
                                 stream);
@@ -701,6 +862,9 @@ extern "C" int sage_pool_max_bwd(const float* dagg, sage_i64 ld_dagg, const floa
     SAGE_CHECK_LAUNCH("pool_indeg_kernel");
     // (a 16-byte variant of this kernel measured the same: 142 us against 200 us all-atomic on a
     // Reddit-shaped batch, where 60 % of the edges end in rows shared by several targets)
+    // (not latency: staging the sources and flags of a segment's edges in LDS ahead of the stores
+    // changed nothing, 146 us; knock-outs on that batch: without the atomics 89, without the plain
+    // stores 141, with neither 78 — see pool_pull_kernel)
     pool_max_bwd_rows_kernel<<<static_cast<unsigned>(num_targets), kBlock, 0, stream>>>(
         dagg, ld_dagg, agg, ld_agg, seg_ptr, src, argmax, num_targets, num_targets_dev, num_features,
         num_sources, indeg, dpre, ld_dpre);
@@ -744,6 +908,94 @@ extern "C" int sage_pool_mean_bwd(const float* dagg, sage_i64 ld_dagg, const flo
       dagg, ld_dagg, p, ld_p, seg_ptr, src, num_targets, num_targets_dev, num_features, num_sources, indeg,
       dpre, ld_dpre);
   SAGE_CHECK_LAUNCH("pool_mean_bwd_rows_kernel");
+  return SAGE_OK;
+}
+
+extern "C" size_t sage_pool_reverse_edges_workspace_bytes(sage_i64 num_sources) {
+  if (num_sources < 0) return 0;
+  return align_up(scan32_temp_bytes(static_cast<size_t>(num_sources) + 1), 256) + 256;
+}
+
+extern "C" int sage_pool_reverse_edges(const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                                       const sage_i64* num_targets_dev, sage_i64 num_sources, int* count,
+                                       int* rev_ptr, int* rev, sage_i64 rev_cap, void* workspace,
+                                       size_t workspace_bytes, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  SAGE_REQUIRE(num_targets >= 0 && num_sources >= 0 && rev_cap >= 0, SAGE_EINVAL,
+               "sage_pool_reverse_edges: negative size");
+  SAGE_REQUIRE(num_targets < (1ll << 23) && num_sources < (1ll << 31) - 1 && rev_cap < (1ll << 31), SAGE_EINVAL,
+               "sage_pool_reverse_edges: a list entry is target * 256 + offset in 32 bits (targets below 2^23)");
+  SAGE_REQUIRE(seg_ptr && src && count && rev_ptr && (rev || rev_cap == 0) && workspace, SAGE_EINVAL,
+               "sage_pool_reverse_edges: NULL pointer argument");
+  SAGE_REQUIRE(workspace_bytes >= sage_pool_reverse_edges_workspace_bytes(num_sources), SAGE_EWORKSPACE,
+               "sage_pool_reverse_edges: workspace too small");
+  zero_i32_kernel<<<static_cast<unsigned>(cdiv(num_sources + 1, kBlock)), kBlock, 0, stream>>>(count, num_sources + 1);
+  SAGE_CHECK_LAUNCH("zero_i32_kernel");
+  if (num_targets > 0 && num_sources > 0) {
+    pool_indeg_kernel<<<static_cast<unsigned>(num_targets), kWave, 0, stream>>>(
+        seg_ptr, src, num_targets, num_targets_dev, num_sources, count);
+    SAGE_CHECK_LAUNCH("pool_indeg_kernel");
+  }
+  Carver ws(workspace);
+  size_t scan_bytes = scan32_temp_bytes(static_cast<size_t>(num_sources) + 1);
+  void* scan_tmp = ws.take<char>(scan_bytes);
+  SAGE_CHECK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, count, rev_ptr, 0,
+                                         static_cast<size_t>(num_sources) + 1, rocprim::plus<int>(), stream),
+                 "scan(in-degrees)");
+  if (num_targets > 0 && num_sources > 0) {
+    pool_reverse_fill_kernel<<<static_cast<unsigned>(num_targets), kWave, 0, stream>>>(
+        seg_ptr, src, num_targets, num_targets_dev, num_sources, count, rev_ptr, rev, rev_cap);
+    SAGE_CHECK_LAUNCH("pool_reverse_fill_kernel");
+  }
+  return SAGE_OK;
+}
+
+namespace {
+int pool_pull_check(const char* who, const float* dagg, sage_i64 ld_dagg, const int* rev_ptr, const int* rev,
+                    sage_i64 num_sources, int num_features, float* dpre, sage_i64 ld_dpre) {
+  const sage_i64 padded = (static_cast<sage_i64>(num_features) + 3) / 4 * 4;
+  SAGE_REQUIRE(num_features > 0 && num_sources >= 0 && ld_dagg >= padded && ld_dpre >= padded, SAGE_EINVAL,
+               "%s: bad shape (rows must hold num_features rounded up to a multiple of 4)", who);
+  if (num_sources == 0) return SAGE_OK;
+  SAGE_REQUIRE(dagg && rev_ptr && rev && dpre, SAGE_EINVAL, "%s: NULL pointer argument", who);
+  SAGE_REQUIRE(reinterpret_cast<uintptr_t>(dagg) % 16 == 0 && ld_dagg % 4 == 0 &&
+                   reinterpret_cast<uintptr_t>(dpre) % 16 == 0 && ld_dpre % 4 == 0,
+               SAGE_EINVAL, "%s: rows of dagg / dpre must be 16-byte aligned (sage_pool_max_bwd / _mean_bwd take any)", who);
+  return SAGE_OK;
+}
+}  // namespace
+
+extern "C" int sage_pool_max_bwd_pull(const float* dagg, sage_i64 ld_dagg, const unsigned char* arg8,
+                                      sage_i64 ld_arg8, const int* rev_ptr, const int* rev, sage_i64 num_sources,
+                                      const sage_i64* num_sources_dev, int num_features, float* dpre,
+                                      sage_i64 ld_dpre, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int rc = pool_pull_check("sage_pool_max_bwd_pull", dagg, ld_dagg, rev_ptr, rev, num_sources, num_features, dpre, ld_dpre);
+  if (rc != SAGE_OK || num_sources == 0) return rc;
+  SAGE_REQUIRE(arg8 && reinterpret_cast<uintptr_t>(arg8) % 4 == 0 && ld_arg8 % 4 == 0 &&
+                   ld_arg8 >= (static_cast<sage_i64>(num_features) + 3) / 4 * 4,
+               SAGE_EINVAL, "sage_pool_max_bwd_pull: arg8 NULL, or its rows not 4-byte aligned / shorter than the padded width");
+  pool_pull_kernel<true><<<static_cast<unsigned>(cdiv(num_sources, kWavesPerBlock)), kBlock, 0, stream>>>(
+      dagg, ld_dagg, arg8, ld_arg8, nullptr, 0, nullptr, rev_ptr, rev, num_sources, num_sources_dev, num_features,
+      dpre, ld_dpre);
+  SAGE_CHECK_LAUNCH("pool_pull_kernel(max)");
+  return SAGE_OK;
+}
+
+extern "C" int sage_pool_mean_bwd_pull(const float* dagg, sage_i64 ld_dagg, const float* p, sage_i64 ld_p,
+                                       const sage_i64* seg_ptr, const int* rev_ptr, const int* rev,
+                                       sage_i64 num_sources, const sage_i64* num_sources_dev, int num_features,
+                                       float* dpre, sage_i64 ld_dpre, void* stream_) {
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  const int rc = pool_pull_check("sage_pool_mean_bwd_pull", dagg, ld_dagg, rev_ptr, rev, num_sources, num_features, dpre, ld_dpre);
+  if (rc != SAGE_OK || num_sources == 0) return rc;
+  SAGE_REQUIRE(p && seg_ptr && p != dpre && reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld_p % 4 == 0 &&
+                   ld_p >= (static_cast<sage_i64>(num_features) + 3) / 4 * 4,
+               SAGE_EINVAL, "sage_pool_mean_bwd_pull: p / seg_ptr NULL, dpre aliasing p, or rows of p not 16-byte aligned");
+  pool_pull_kernel<false><<<static_cast<unsigned>(cdiv(num_sources, kWavesPerBlock)), kBlock, 0, stream>>>(
+      dagg, ld_dagg, nullptr, 0, p, ld_p, seg_ptr, rev_ptr, rev, num_sources, num_sources_dev, num_features,
+      dpre, ld_dpre);
+  SAGE_CHECK_LAUNCH("pool_pull_kernel(mean)");
   return SAGE_OK;
 }
 

@@ -366,6 +366,23 @@ class SageTrainEngine:
             return act
         self.acts = [make_act() for _ in range(nvar)]
         self.act = self.acts[0]   # per layer: dict of static buffers (variant 0)
+        # Pooling aggregators, layer 0: the edge pass of the backward PULLED by the source rows
+        # (sage_pool_max_bwd_pull / sage_pool_mean_bwd_pull: every row of d pre stored once, no
+        # atomics, no in-degree launches in the step, no zero-fill by the pool Linear) from the
+        # batch's edges listed per source row, which the sampler's stream builds behind the sampler
+        # (sage_pool_reverse_edges, per sample slot); max keeps its arg-max as one byte per (target,
+        # column).  The B seed rows of the layers above stay with the pushed pass.
+        # SAGE_NO_POOL_PULL=1: the pushed pass with its in-degree workspace for layer 0 too;
+        # SAGE_POOL_PULL_ALL=1: pulled whatever the batch's size (below 4096 targets the lists cost
+        # the sampler's stream more than the step gains; tests).
+        self.rev = None
+        a0 = self.act[0]
+        if (self.pool and (a0['t_cap'] >= 4096 or os.environ.get('SAGE_POOL_PULL_ALL')) and a0['t_cap'] < 2 ** 23
+                and not os.environ.get('SAGE_NO_POOL_PULL')
+                and (self.reduce != 'max' or max(fan) <= 255)):
+            self.rev = [ops.ReverseEdges(a0['s_cap'], edge_cap, dev) for _ in range(self.nslots)]
+            if self.reduce == 'max':
+                a0['arg8'] = torch.zeros((a0['t_cap'], (a0['fin'] + 15) // 16 * 16), dtype=torch.uint8, device=dev)
         if self.unsup:
             self.pos_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
             self.neg_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
@@ -502,6 +519,9 @@ class SageTrainEngine:
         if self.writers is not None:
             buf = self.bufs[slot]
             ops.count_row_writers(buf.seg_ptr, buf.src, self.B, self.writers[slot], max_edges=self.B * max(self.fanout[0], 1))
+        if self.rev is not None:      # (pooling) layer 0's edges per source row, for its backward's edge pass
+            a, buf = self.act[0], self.bufs[slot]
+            self.rev[slot].build(buf.seg_ptr, buf.src, a['t_cap'], num_targets_dev=self.n_dev[slot][a['hop']])
 
     def _next_stamp(self, stream=None):
         """Stamps of the relabel table must grow (sage_hip.h); when the 32-bit range is used up,
@@ -601,6 +621,10 @@ class SageTrainEngine:
             return
         if self.pool:
             self._pool_forward(slot, 0, self.features, buf.node)
+            if 'arg8' in a:
+                ops.pool_max_fwd(a['P'], buf.seg_ptr, buf.src, a['t_cap'], max(self.fanout), self.agg0[slot], a['arg8'],
+                                 num_targets_dev=self.n_dev[slot][a['hop']])
+                return
             ops.gather_reduce_fwd(a['P'], buf.seg_ptr, buf.src, a['t_cap'], self.reduce,
                                   num_targets_dev=self.n_dev[slot][a['hop']], out=self.agg0[slot],
                                   want_argmax=self.reduce == 'max', argmax=a.get('argmax'), events=events)
@@ -612,10 +636,11 @@ class SageTrainEngine:
     def _pool_forward(self, slot, i, x, node_map):
         """P = relu(x[rows] @ pool.weight^T + pool.bias) over the layer's source rows."""
         a, layer = self.act[i], self.model.layers[i]
-        # the same stores hand dpre back zeroed for this step's masked scatter
+        # the same stores hand dpre back zeroed for this step's masked scatter (the pulled pass of
+        # layer 0 stores every row itself)
         ops.pool_linear_fwd(x, layer.pool.weight, layer.pool.bias, m=a['s_cap'],
                             m_dev=self.n_dev[slot][a['src_hop']], rows=node_map, out=a['P'],
-                            dpre=a['dpre'])
+                            dpre=None if (i == 0 and self.rev is not None) else a['dpre'])
 
     @staticmethod
     def _lstm_blocks(fdim):
@@ -924,7 +949,12 @@ class SageTrainEngine:
         # 0; the B seed rows of the layers above are routed with atomics throughout
         # (max_pool 1.199 against 1.212 ms per step, mean_pool unchanged; scratch/pool_indeg_ab.sh)
         indeg = a['indeg'] if (t_cap >= 4096 or os.environ.get('SAGE_POOL_INDEG_ALL')) else None
-        if self.reduce == 'max':
+        if i == 0 and self.rev is not None:
+            if self.reduce == 'max':
+                lib.pool_max_bwd_pull(a['dagg'], a['arg8'], self.rev[slot], a['dpre'], num_sources_dev=s_dev)
+            else:
+                lib.pool_mean_bwd_pull(a['dagg'], a['P'], buf.seg_ptr, self.rev[slot], a['dpre'], num_sources_dev=s_dev)
+        elif self.reduce == 'max':
             agg_i = self.agg0[slot] if i == 0 else a['agg']
             # (the bias gradient = column sums of d pre for max as for mean: the weight-gradient
             # kernel adds them up from the rows it stages anyway, ~6 us against a 13 us pass of

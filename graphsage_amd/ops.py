@@ -722,6 +722,85 @@ def pool_mean_bwd(dagg, p, seg_ptr, src, num_targets, dpre, num_targets_dev=None
     return dpre
 
 
+class ReverseEdges:
+    """The edges of a sampled hop listed per SOURCE row (sage_pool_reverse_edges): static buffers for
+    up to `num_sources` rows and `edge_cap` edges, refilled by `build`."""
+
+    def __init__(self, num_sources, edge_cap, device):
+        lib = _lib.load()
+        self.num_sources, self.edge_cap = int(num_sources), int(edge_cap)
+        self.count = torch.zeros(self.num_sources + 1, dtype=torch.int32, device=device)
+        self.ptr = torch.zeros(self.num_sources + 1, dtype=torch.int32, device=device)
+        self.entries = torch.zeros(max(self.edge_cap, 1), dtype=torch.int32, device=device)
+        self.ws_bytes = int(lib.sage_pool_reverse_edges_workspace_bytes(self.num_sources))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+
+    def build(self, seg_ptr, src, num_targets, num_targets_dev=None):
+        lib = _lib.load()
+        T = int(num_targets)
+        if seg_ptr.numel() < T + 1:
+            raise RuntimeError("ReverseEdges.build: seg_ptr shorter than num_targets + 1")
+        rc = lib.sage_pool_reverse_edges(_vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), T,
+                                         _count(num_targets_dev, "num_targets_dev"), self.num_sources,
+                                         _p(self.count, torch.int32, "count"), _p(self.ptr, torch.int32, "ptr"),
+                                         _p(self.entries, torch.int32, "entries"), self.edge_cap,
+                                         self.ws.data_ptr(), self.ws_bytes, _stream())
+        _lib.check(rc, "sage_pool_reverse_edges")
+        return self
+
+
+def pool_max_fwd(p, seg_ptr, src, num_targets, max_segment, out, arg8, num_targets_dev=None):
+    """out[t] = max over the rows p[src[e]] of target t's edges (p = relu(pool(x)), reference
+    layers/sage.py:201-210) with the arg-max edge kept as one byte per (target, column) in arg8
+    (uint8 [T, >= F rounded up to 4]): the edge's offset in the segment, 255 = no gradient."""
+    lib = _lib.load()
+    pp, ld_p = _mat(p, "p")
+    op, ld_o = _mat(out, "out")
+    T, F = int(num_targets), p.size(1)
+    if (out.size(1) != F or out.size(0) < T or seg_ptr.numel() < T + 1 or arg8.dtype != torch.uint8 or arg8.dim() != 2
+            or arg8.size(0) < T or arg8.stride(1) != 1):
+        raise RuntimeError("pool_max_fwd: shape mismatch (arg8: uint8 [T, F padded to 4])")
+    rc = lib.sage_pool_max_fwd(pp, ld_p, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"), T,
+                               _count(num_targets_dev, "num_targets_dev"), F, int(max_segment), op, ld_o,
+                               arg8.data_ptr(), arg8.stride(0), _stream())
+    _lib.check(rc, "sage_pool_max_fwd")
+    return out
+
+
+def pool_max_bwd_pull(dagg, arg8, rev, dpre, num_sources_dev=None):
+    """pool_max_bwd pulled by the source rows: dpre[s] = sum over the in-edges (t, j) of row s of
+    dagg[t, f] where arg8[t, f] == j; rows [0, rev.num_sources) of dpre are stored whole."""
+    lib = _lib.load()
+    gp, ld_g = _mat(dagg, "dagg")
+    zp, ld_z = _mat(dpre, "dpre")
+    F = dagg.size(1)
+    if dpre.size(1) != F or dpre.size(0) < rev.num_sources or arg8.dtype != torch.uint8 or arg8.stride(1) != 1:
+        raise RuntimeError("pool_max_bwd_pull: shape mismatch")
+    rc = lib.sage_pool_max_bwd_pull(gp, ld_g, arg8.data_ptr(), arg8.stride(0), _p(rev.ptr, torch.int32, "ptr"),
+                                    _p(rev.entries, torch.int32, "entries"), rev.num_sources,
+                                    _count(num_sources_dev, "num_sources_dev"), F, zp, ld_z, _stream())
+    _lib.check(rc, "sage_pool_max_bwd_pull")
+    return dpre
+
+
+def pool_mean_bwd_pull(dagg, p, seg_ptr, rev, dpre, num_sources_dev=None):
+    """pool_mean_bwd pulled by the source rows: dpre[s] = (p[s] > 0) * sum over the in-edges of row
+    s of dagg[t] / deg(t); rows [0, rev.num_sources) of dpre are stored whole."""
+    lib = _lib.load()
+    gp, ld_g = _mat(dagg, "dagg")
+    pp, ld_p = _mat(p, "p")
+    zp, ld_z = _mat(dpre, "dpre")
+    F = dagg.size(1)
+    if p.size(1) != F or dpre.size(1) != F or dpre.size(0) < rev.num_sources or p.size(0) < rev.num_sources:
+        raise RuntimeError("pool_mean_bwd_pull: shape mismatch")
+    rc = lib.sage_pool_mean_bwd_pull(gp, ld_g, pp, ld_p, _vec(seg_ptr, torch.int64, "seg_ptr"),
+                                     _p(rev.ptr, torch.int32, "ptr"), _p(rev.entries, torch.int32, "entries"),
+                                     rev.num_sources, _count(num_sources_dev, "num_sources_dev"), F, zp, ld_z,
+                                     _stream())
+    _lib.check(rc, "sage_pool_mean_bwd_pull")
+    return dpre
+
+
 def l2norm_relu_bwd(dh, y, inv_norm, relu, m=None, m_dev=None, dz=None, clear_dh=False):
     """Backward of relu(normalize(z)).  clear_dh=True zeroes the consumed rows of dh."""
     lib = _lib.load()

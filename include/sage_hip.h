@@ -500,6 +500,43 @@ int sage_pool_mean_bwd(const float* dagg, sage_i64 ld_dagg, const float* p, sage
                        const sage_i64* num_targets_dev, int num_features, float* dpre, sage_i64 ld_dpre,
                        sage_i64 num_sources, int* indeg, void* stream);
 
+/* The same two edge passes PULLED by the source rows (layer 0 of the engine's pooling step; the
+ * reference's scatter of layers/sage.py:209-210 differentiated, as the two entry points above).
+ * sage_pool_reverse_edges lists the live targets' edges per source row: count [num_sources + 1]
+ * (workspace, left zero), rev_ptr [num_sources + 1] (row s's entries are rev[rev_ptr[s] ..
+ * rev_ptr[s + 1])), an entry = target * 256 + min(offset of the edge in the target's segment, 255);
+ * entries of one row come in no fixed order (atomic slots).  It needs nothing but the sampled
+ * batch, so a caller can run it ahead of the step.  Limits: num_targets < 2^23, rev_cap < 2^31;
+ * edges that would not fit rev_cap are dropped.  workspace: sage_pool_reverse_edges_workspace_bytes.
+ * sage_pool_max_fwd: sage_gather_reduce_fwd(max) over rows of p = relu(...) that records the
+ * arg-max edge of (target, column) as ONE byte in arg8 (rows ld_arg8 bytes apart, 4-byte aligned):
+ * the edge's offset in the segment, or 255 where no gradient flows (empty segment, maximum <= 0 —
+ * the relu mask of the routed element); max_segment = the caller's bound on a segment's length,
+ * refused above 255.
+ * sage_pool_max_bwd_pull / sage_pool_mean_bwd_pull: one wave per source row adds up what its
+ * in-edges route to it (max: dagg[t, f] where arg8[t, f] == the entry's offset; mean: dagg[t] /
+ * deg(t), masked by the row's own p > 0) and STORES rows [0, num_sources) (device-side count
+ * num_sources_dev limits them) of dpre, rows without in-edges as zeros: no atomics, no zero-fill
+ * expected.  Rows of dagg, p, dpre 16-byte aligned and padded to a multiple of 4 columns (the
+ * padding of dpre is written with zeros). */
+size_t sage_pool_reverse_edges_workspace_bytes(sage_i64 num_sources);
+int sage_pool_reverse_edges(const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
+                            const sage_i64* num_targets_dev, sage_i64 num_sources, int* count,
+                            int* rev_ptr, int* rev, sage_i64 rev_cap, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int sage_pool_max_fwd(const float* p, sage_i64 ld_p, const sage_i64* seg_ptr, const sage_i64* src,
+                      sage_i64 num_targets, const sage_i64* num_targets_dev, int num_features,
+                      int max_segment, float* out, sage_i64 ld_out, unsigned char* arg8,
+                      sage_i64 ld_arg8, void* stream);
+int sage_pool_max_bwd_pull(const float* dagg, sage_i64 ld_dagg, const unsigned char* arg8,
+                           sage_i64 ld_arg8, const int* rev_ptr, const int* rev, sage_i64 num_sources,
+                           const sage_i64* num_sources_dev, int num_features, float* dpre,
+                           sage_i64 ld_dpre, void* stream);
+int sage_pool_mean_bwd_pull(const float* dagg, sage_i64 ld_dagg, const float* p, sage_i64 ld_p,
+                            const sage_i64* seg_ptr, const int* rev_ptr, const int* rev,
+                            sage_i64 num_sources, const sage_i64* num_sources_dev, int num_features,
+                            float* dpre, sage_i64 ld_dpre, void* stream);
+
 /* Mean softmax cross-entropy over m rows and its gradient (F.cross_entropy of
  * experiments/fig2a/runners/graphsage_runners.py:43 / nn.CrossEntropyLoss of
  * trainers/node_level_graphsage_trainers.py:41).  labels are gathered through

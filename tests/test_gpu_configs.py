@@ -257,18 +257,22 @@ def test_reddit_shape_pool_step_matches_plain_torch(reddit, dev, aggregator):
             assert int(off.sum()) <= 0.01 * off.numel(), (name, int(off.sum()))
 
 
-@pytest.mark.parametrize("fork", [True, False])
+@pytest.mark.parametrize("fork,pull", [(True, True), (False, True), (True, False)])
 @pytest.mark.parametrize("aggregator", ["max_pool", "mean_pool"])
-def test_reddit_shape_pool_engine_step_matches_module_path(reddit, dev, aggregator, fork, monkeypatch):
+def test_reddit_shape_pool_engine_step_matches_module_path(reddit, dev, aggregator, fork, pull, monkeypatch):
     """The same step on the static-shape engine (pool Linear over all sampled nodes into a static
     buffer, gather over its rows, scatter -> relu mask -> pool weight / bias gradients with the
     contraction length read on the device) against the module path checked above: loss, every
     gradient, the parameters after Adam.  fork: the large weight gradients on a stream of their
     own beside the aggregate path (the default; the first step records the fork / join into the
-    call tape, the second replays them) or everything on one stream (SAGE_NO_POOL_FORK=1)."""
+    call tape, the second replays them) or everything on one stream (SAGE_NO_POOL_FORK=1).
+    pull: layer 0's edge pass pulled by the source rows from the per-source edge lists built behind
+    the sampler (the default at this size) or pushed from the targets (SAGE_NO_POOL_PULL=1)."""
     import copy
     if not fork:
         monkeypatch.setenv("SAGE_NO_POOL_FORK", "1")
+    if not pull:
+        monkeypatch.setenv("SAGE_NO_POOL_PULL", "1")
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import NeighborSampler
@@ -278,7 +282,7 @@ def test_reddit_shape_pool_engine_step_matches_module_path(reddit, dev, aggregat
     ref_model = copy.deepcopy(model)
     engine = SageTrainEngine(model, NeighborSampler.from_graph(graph, [25, 10], seed=0), graph.features(data),
                              graph.labels(data), B, lr=1e-3, keep_grads=True)
-    assert (engine.pool_fork is not None) == fork
+    assert (engine.pool_fork is not None) == fork and (engine.rev is not None) == pull
     seeds = torch.randperm(data.num_nodes, generator=torch.Generator().manual_seed(2))[:B].to(dev)
     loss = engine.step(seeds, counter=11)
     st = engine.buf.state.tolist()

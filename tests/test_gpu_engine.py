@@ -12,11 +12,17 @@ from tests.helpers import assert_trajectories_close
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("aggregator", ["mean", "sum", "max", "gcn", "max_pool", "mean_pool", "lstm"])
+@pytest.mark.parametrize("aggregator", ["mean", "sum", "max", "gcn", "max_pool", "mean_pool", "lstm",
+                                        "max_pool/pull", "mean_pool/pull"])
 def test_engine_matches_module_path(dev, aggregator, monkeypatch):
     from graphsage_amd import settings
     from graphsage_amd.datasets import planted_partition
     monkeypatch.setattr(settings, "LSTM_NUM_INPUTS", 4)      # fan-outs 5 / 3: truncation and padding both occur
+    # "/pull": layer 0's edge pass pulled by the source rows (what Reddit-sized batches take by
+    # themselves: engine.rev, sage_pool_reverse_edges behind the sampler)
+    aggregator, _, pull = aggregator.partition("/")
+    if pull:
+        monkeypatch.setenv("SAGE_POOL_PULL_ALL", "1")
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
     from graphsage_amd.samplers import NeighborSampler, UniformLoader
@@ -30,6 +36,7 @@ def test_engine_matches_module_path(dev, aggregator, monkeypatch):
     graph = device_graph(data)
     engine = SageTrainEngine(model_b, NeighborSampler(data, [5, 3], seed=7), graph.features(data),
                              graph.labels(data), B, lr=1e-2, keep_grads=True)
+    assert (engine.rev is not None) == bool(pull)
     opt = torch.optim.Adam(model_a.parameters(), lr=1e-2)
     for b, batch in enumerate(loader):
         opt.zero_grad()

@@ -502,6 +502,76 @@ def test_pool_mean_bwd_matches_scatter_then_relu_mask(dev, T, S, F, fan):
         assert float((dpre - want).abs().max()) <= 2e-5 * scale      # atomics: order of the sums only
 
 
+@pytest.mark.parametrize("T,S,F,fan", [(700, 2500, 602, 10), (64, 90, 37, 3), (300, 50, 1100, 25), (40, 3, 8, 200)])
+def test_pool_bwd_pulled_by_source_rows_matches_the_pushed_passes(dev, T, S, F, fan):
+    """sage_pool_reverse_edges / sage_pool_max_fwd / sage_pool_max_bwd_pull / sage_pool_mean_bwd_pull
+    against the edge passes pushed from the targets (sage_pool_max_bwd / sage_pool_mean_bwd, held
+    to torch above): the lists themselves, the one-byte arg-max, every row of dpre stored over
+    garbage (rows without in-edges as zeros), the device-side source count, rows with more than 64
+    in-edges (S = 3), a source repeated inside a segment."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(15)
+    deg = torch.randint(0, fan + 1, (T,), generator=g, device=dev)
+    deg[::17] = 0
+    seg_ptr = torch.zeros(T + 1, dtype=torch.int64, device=dev)
+    seg_ptr[1:] = deg.cumsum(0)
+    E = int(seg_ptr[-1])
+    src = torch.randint(0, S - 1, (E,), generator=g, device=dev)      # row S - 1 has no in-edge
+    P = ops.empty_rows(S, F, dev)
+    P.copy_(torch.randn(S, F, generator=g, device=dev).relu())
+    live = T - 9
+    live_e = int(seg_ptr[live])
+    count = torch.tensor([live], dtype=torch.int64, device=dev)
+    dagg = ops.empty_rows(T, F, dev)
+    dagg.copy_(torch.randn(T, F, generator=g, device=dev))
+
+    rev = ops.ReverseEdges(S, E, dev).build(seg_ptr, src, T, num_targets_dev=count)
+    indeg = torch.bincount(src[:live_e], minlength=S)
+    assert int(rev.count.abs().max()) == 0                    # every counted slot was handed out
+    assert torch.equal(rev.ptr.long()[1:], indeg.cumsum(0)) and int(rev.ptr[0]) == 0
+    tgt = torch.repeat_interleave(torch.arange(T, device=dev), deg)[:live_e]
+    want_entries = tgt * 256 + (torch.arange(live_e, device=dev) - seg_ptr[tgt]).clamp(max=255)
+    row_of = torch.repeat_interleave(torch.arange(S, device=dev), indeg)
+    got_keys = (row_of << 40) + rev.entries[:live_e].long()
+    want_keys = (src[:live_e] << 40) + want_entries
+    assert torch.equal(got_keys.sort().values, want_keys.sort().values)
+
+    # max: forward with the one-byte arg-max
+    agg, argmax = ops.gather_reduce_fwd(P, seg_ptr, src, T, 'max', num_targets_dev=count, want_argmax=True)
+    fpad = (F + 3) // 4 * 4
+    arg8 = torch.full((T, fpad), 7, dtype=torch.uint8, device=dev)
+    agg8 = ops.empty_rows(T, F, dev)
+    ops.pool_max_fwd(P, seg_ptr, src, T, fan, agg8, arg8, num_targets_dev=count)
+    assert torch.equal(agg8[:live], agg[:live])
+    off = argmax[:live] - seg_ptr[:live, None]
+    want8 = torch.where((argmax[:live] >= 0) & (agg[:live] > 0), off, torch.full_like(off, 255))
+    assert torch.equal(arg8[:live, :F].long(), want8)
+    assert int(arg8[live:].min()) == 7 and (fpad == F or int(arg8[:, F:].min()) == 7)
+    with pytest.raises(RuntimeError, match="one-byte"):
+        ops.pool_max_fwd(P, seg_ptr, src, T, 256, agg8, arg8)
+    want = ops.empty_rows(S, F, dev, zero=True)
+    ops.pool_max_bwd(dagg, agg, seg_ptr, src, argmax, T, want, num_targets_dev=count)
+    scale = max(1.0, float(want.abs().max()))
+    dpre = ops.empty_rows(S, F, dev)
+    dpre.fill_(3.0)
+    ops.pool_max_bwd_pull(dagg, arg8, rev, dpre)
+    assert float((dpre - want).abs().max()) <= 1e-5 * scale
+    assert float(dpre[S - 1].abs().max()) == 0.0
+    dpre.fill_(3.0)
+    ops.pool_max_bwd_pull(dagg, arg8, rev, dpre, num_sources_dev=torch.tensor([S - 2], dtype=torch.int64, device=dev))
+    assert float((dpre[:S - 2] - want[:S - 2]).abs().max()) <= 1e-5 * scale
+    assert float(dpre[S - 2:].min()) == 3.0 and float(dpre[S - 2:].max()) == 3.0
+
+    # mean
+    want = ops.empty_rows(S, F, dev, zero=True)
+    ops.pool_mean_bwd(dagg, P, seg_ptr, src, T, want, num_targets_dev=count)
+    scale = max(1.0, float(want.abs().max()))
+    dpre.fill_(3.0)
+    ops.pool_mean_bwd_pull(dagg, P, seg_ptr, rev, dpre)
+    assert float((dpre - want).abs().max()) <= 2e-5 * scale
+    assert float(dpre[S - 1].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("m,n", [(512, 41), (37, 7), (300, 200)])
 def test_softmax_xent_rows_matches_single_workgroup_kernel(dev, m, n):
     """sage_softmax_xent_rows (wave per row, many workgroups, fixed-order mean) against
