@@ -82,8 +82,9 @@ SIGNATURES = {
     "sage_pool_reverse_edges_workspace_bytes": (c_size_t, [c_int64]),
     "sage_pool_reverse_edges": (c_int, [_P, _P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P, c_size_t, _P]),
     "sage_pool_max_fwd": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, c_int, _P, c_int64, _P, c_int64, _P]),
-    "sage_pool_max_bwd_pull": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, _P, c_int, _P, c_int64, _P]),
-    "sage_pool_mean_bwd_pull": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, _P, c_int, _P, c_int64, _P]),
+    "sage_pool_max_bwd_pull": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int64, _P, c_int, _P, c_int64, _P]),
+    "sage_pool_mean_bwd_pull": (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int64, c_int64, _P, c_int, _P, c_int64,
+                                        _P]),
     "sage_softmax_xent": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, c_int64,
                                   _P]),
     "sage_softmax_xent_rows": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_float, _P, _P, _P, c_int64, _P]),

@@ -497,13 +497,16 @@ __global__ void __launch_bounds__(kBlock)
 pool_pull_kernel(const float* __restrict__ dagg, int64_t ld_dagg, const uint8_t* __restrict__ arg8,
                  int64_t ld_arg8, const float* __restrict__ p, int64_t ld_p,
                  const int64_t* __restrict__ seg_ptr, const int* __restrict__ rev_ptr,
-                 const int* __restrict__ rev, int64_t num_sources, const int64_t* __restrict__ num_sources_dev,
-                 int num_features, float* __restrict__ dpre, int64_t ld_dpre) {
+                 const int* __restrict__ rev, int rev_cap, int64_t num_sources,
+                 const int64_t* __restrict__ num_sources_dev, int num_features, float* __restrict__ dpre,
+                 int64_t ld_dpre) {
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t ns = dev_count(num_sources_dev, num_sources);
   const int64_t s = static_cast<int64_t>(blockIdx.x) * kWavesPerBlock + threadIdx.x / kWave;
   if (s >= ns) return;
-  const int b0 = rev_ptr[s], b1 = rev_ptr[s + 1];
+  int b0 = rev_ptr[s], b1 = rev_ptr[s + 1];
+  if (b0 > rev_cap) b0 = rev_cap;      // (edges that did not fit the list were dropped by the fill)
+  if (b1 > rev_cap) b1 = rev_cap;
   for (int f0 = 0; f0 < num_features; f0 += kWave * kPullCols * kPullPasses) {
     float acc[kPullPasses][kPullCols];
     bool live[kPullPasses];
@@ -952,9 +955,11 @@ extern "C" int sage_pool_reverse_edges(const sage_i64* seg_ptr, const sage_i64* 
 
 namespace {
 int pool_pull_check(const char* who, const float* dagg, sage_i64 ld_dagg, const int* rev_ptr, const int* rev,
-                    sage_i64 num_sources, int num_features, float* dpre, sage_i64 ld_dpre) {
+                    sage_i64 rev_cap, sage_i64 num_sources, int num_features, float* dpre, sage_i64 ld_dpre) {
   const sage_i64 padded = (static_cast<sage_i64>(num_features) + 3) / 4 * 4;
-  SAGE_REQUIRE(num_features > 0 && num_sources >= 0 && ld_dagg >= padded && ld_dpre >= padded, SAGE_EINVAL,
+  SAGE_REQUIRE(num_features > 0 && num_sources >= 0 && rev_cap >= 0 && rev_cap < (1ll << 31) && ld_dagg >= padded &&
+                   ld_dpre >= padded,
+               SAGE_EINVAL,
                "%s: bad shape (rows must hold num_features rounded up to a multiple of 4)", who);
   if (num_sources == 0) return SAGE_OK;
   SAGE_REQUIRE(dagg && rev_ptr && rev && dpre, SAGE_EINVAL, "%s: NULL pointer argument", who);
@@ -966,35 +971,35 @@ int pool_pull_check(const char* who, const float* dagg, sage_i64 ld_dagg, const 
 }  // namespace
 
 extern "C" int sage_pool_max_bwd_pull(const float* dagg, sage_i64 ld_dagg, const unsigned char* arg8,
-                                      sage_i64 ld_arg8, const int* rev_ptr, const int* rev, sage_i64 num_sources,
-                                      const sage_i64* num_sources_dev, int num_features, float* dpre,
-                                      sage_i64 ld_dpre, void* stream_) {
+                                      sage_i64 ld_arg8, const int* rev_ptr, const int* rev, sage_i64 rev_cap,
+                                      sage_i64 num_sources, const sage_i64* num_sources_dev, int num_features,
+                                      float* dpre, sage_i64 ld_dpre, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int rc = pool_pull_check("sage_pool_max_bwd_pull", dagg, ld_dagg, rev_ptr, rev, num_sources, num_features, dpre, ld_dpre);
+  const int rc = pool_pull_check("sage_pool_max_bwd_pull", dagg, ld_dagg, rev_ptr, rev, rev_cap, num_sources, num_features, dpre, ld_dpre);
   if (rc != SAGE_OK || num_sources == 0) return rc;
   SAGE_REQUIRE(arg8 && reinterpret_cast<uintptr_t>(arg8) % 4 == 0 && ld_arg8 % 4 == 0 &&
                    ld_arg8 >= (static_cast<sage_i64>(num_features) + 3) / 4 * 4,
                SAGE_EINVAL, "sage_pool_max_bwd_pull: arg8 NULL, or its rows not 4-byte aligned / shorter than the padded width");
   pool_pull_kernel<true><<<static_cast<unsigned>(cdiv(num_sources, kWavesPerBlock)), kBlock, 0, stream>>>(
-      dagg, ld_dagg, arg8, ld_arg8, nullptr, 0, nullptr, rev_ptr, rev, num_sources, num_sources_dev, num_features,
-      dpre, ld_dpre);
+      dagg, ld_dagg, arg8, ld_arg8, nullptr, 0, nullptr, rev_ptr, rev, static_cast<int>(rev_cap), num_sources,
+      num_sources_dev, num_features, dpre, ld_dpre);
   SAGE_CHECK_LAUNCH("pool_pull_kernel(max)");
   return SAGE_OK;
 }
 
 extern "C" int sage_pool_mean_bwd_pull(const float* dagg, sage_i64 ld_dagg, const float* p, sage_i64 ld_p,
                                        const sage_i64* seg_ptr, const int* rev_ptr, const int* rev,
-                                       sage_i64 num_sources, const sage_i64* num_sources_dev, int num_features,
-                                       float* dpre, sage_i64 ld_dpre, void* stream_) {
+                                       sage_i64 rev_cap, sage_i64 num_sources, const sage_i64* num_sources_dev,
+                                       int num_features, float* dpre, sage_i64 ld_dpre, void* stream_) {
   hipStream_t stream = static_cast<hipStream_t>(stream_);
-  const int rc = pool_pull_check("sage_pool_mean_bwd_pull", dagg, ld_dagg, rev_ptr, rev, num_sources, num_features, dpre, ld_dpre);
+  const int rc = pool_pull_check("sage_pool_mean_bwd_pull", dagg, ld_dagg, rev_ptr, rev, rev_cap, num_sources, num_features, dpre, ld_dpre);
   if (rc != SAGE_OK || num_sources == 0) return rc;
   SAGE_REQUIRE(p && seg_ptr && p != dpre && reinterpret_cast<uintptr_t>(p) % 16 == 0 && ld_p % 4 == 0 &&
                    ld_p >= (static_cast<sage_i64>(num_features) + 3) / 4 * 4,
                SAGE_EINVAL, "sage_pool_mean_bwd_pull: p / seg_ptr NULL, dpre aliasing p, or rows of p not 16-byte aligned");
   pool_pull_kernel<false><<<static_cast<unsigned>(cdiv(num_sources, kWavesPerBlock)), kBlock, 0, stream>>>(
-      dagg, ld_dagg, nullptr, 0, p, ld_p, seg_ptr, rev_ptr, rev, num_sources, num_sources_dev, num_features,
-      dpre, ld_dpre);
+      dagg, ld_dagg, nullptr, 0, p, ld_p, seg_ptr, rev_ptr, rev, static_cast<int>(rev_cap), num_sources,
+      num_sources_dev, num_features, dpre, ld_dpre);
   SAGE_CHECK_LAUNCH("pool_pull_kernel(mean)");
   return SAGE_OK;
 }

@@ -777,7 +777,7 @@ def pool_max_bwd_pull(dagg, arg8, rev, dpre, num_sources_dev=None):
     if dpre.size(1) != F or dpre.size(0) < rev.num_sources or arg8.dtype != torch.uint8 or arg8.stride(1) != 1:
         raise RuntimeError("pool_max_bwd_pull: shape mismatch")
     rc = lib.sage_pool_max_bwd_pull(gp, ld_g, arg8.data_ptr(), arg8.stride(0), _p(rev.ptr, torch.int32, "ptr"),
-                                    _p(rev.entries, torch.int32, "entries"), rev.num_sources,
+                                    _p(rev.entries, torch.int32, "entries"), rev.edge_cap, rev.num_sources,
                                     _count(num_sources_dev, "num_sources_dev"), F, zp, ld_z, _stream())
     _lib.check(rc, "sage_pool_max_bwd_pull")
     return dpre
@@ -795,8 +795,8 @@ def pool_mean_bwd_pull(dagg, p, seg_ptr, rev, dpre, num_sources_dev=None):
         raise RuntimeError("pool_mean_bwd_pull: shape mismatch")
     rc = lib.sage_pool_mean_bwd_pull(gp, ld_g, pp, ld_p, _vec(seg_ptr, torch.int64, "seg_ptr"),
                                      _p(rev.ptr, torch.int32, "ptr"), _p(rev.entries, torch.int32, "entries"),
-                                     rev.num_sources, _count(num_sources_dev, "num_sources_dev"), F, zp, ld_z,
-                                     _stream())
+                                     rev.edge_cap, rev.num_sources, _count(num_sources_dev, "num_sources_dev"), F,
+                                     zp, ld_z, _stream())
     _lib.check(rc, "sage_pool_mean_bwd_pull")
     return dpre
 

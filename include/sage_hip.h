@@ -517,8 +517,9 @@ int sage_pool_mean_bwd(const float* dagg, sage_i64 ld_dagg, const float* p, sage
  * in-edges route to it (max: dagg[t, f] where arg8[t, f] == the entry's offset; mean: dagg[t] /
  * deg(t), masked by the row's own p > 0) and STORES rows [0, num_sources) (device-side count
  * num_sources_dev limits them) of dpre, rows without in-edges as zeros: no atomics, no zero-fill
- * expected.  Rows of dagg, p, dpre 16-byte aligned and padded to a multiple of 4 columns (the
- * padding of dpre is written with zeros). */
+ * expected; rev_cap as given to sage_pool_reverse_edges (list positions beyond it are not read:
+ * the edges it dropped contribute nothing).  Rows of dagg, p, dpre 16-byte aligned and padded to
+ * a multiple of 4 columns (the padding of dpre is written with zeros). */
 size_t sage_pool_reverse_edges_workspace_bytes(sage_i64 num_sources);
 int sage_pool_reverse_edges(const sage_i64* seg_ptr, const sage_i64* src, sage_i64 num_targets,
                             const sage_i64* num_targets_dev, sage_i64 num_sources, int* count,
@@ -529,13 +530,13 @@ int sage_pool_max_fwd(const float* p, sage_i64 ld_p, const sage_i64* seg_ptr, co
                       int max_segment, float* out, sage_i64 ld_out, unsigned char* arg8,
                       sage_i64 ld_arg8, void* stream);
 int sage_pool_max_bwd_pull(const float* dagg, sage_i64 ld_dagg, const unsigned char* arg8,
-                           sage_i64 ld_arg8, const int* rev_ptr, const int* rev, sage_i64 num_sources,
-                           const sage_i64* num_sources_dev, int num_features, float* dpre,
-                           sage_i64 ld_dpre, void* stream);
+                           sage_i64 ld_arg8, const int* rev_ptr, const int* rev, sage_i64 rev_cap,
+                           sage_i64 num_sources, const sage_i64* num_sources_dev, int num_features,
+                           float* dpre, sage_i64 ld_dpre, void* stream);
 int sage_pool_mean_bwd_pull(const float* dagg, sage_i64 ld_dagg, const float* p, sage_i64 ld_p,
                             const sage_i64* seg_ptr, const int* rev_ptr, const int* rev,
-                            sage_i64 num_sources, const sage_i64* num_sources_dev, int num_features,
-                            float* dpre, sage_i64 ld_dpre, void* stream);
+                            sage_i64 rev_cap, sage_i64 num_sources, const sage_i64* num_sources_dev,
+                            int num_features, float* dpre, sage_i64 ld_dpre, void* stream);
 
 /* Mean softmax cross-entropy over m rows and its gradient (F.cross_entropy of
  * experiments/fig2a/runners/graphsage_runners.py:43 / nn.CrossEntropyLoss of

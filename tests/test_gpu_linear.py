@@ -570,6 +570,20 @@ def test_pool_bwd_pulled_by_source_rows_matches_the_pushed_passes(dev, T, S, F, 
     ops.pool_mean_bwd_pull(dagg, P, seg_ptr, rev, dpre)
     assert float((dpre - want).abs().max()) <= 2e-5 * scale
     assert float(dpre[S - 1].abs().max()) == 0.0
+    # a list too short for the batch: the edges that do not fit are dropped, nothing is read or
+    # written beyond it — rows whose entries all fit still come out whole
+    small = ops.ReverseEdges(S, live_e // 2, dev)
+    guard = torch.full((live_e // 2 + 64,), -1, dtype=torch.int32, device=dev)
+    small.entries = guard[:max(live_e // 2, 1)]
+    small.build(seg_ptr, src, T, num_targets_dev=count)
+    assert torch.equal(small.ptr, rev.ptr)
+    assert int(guard[max(live_e // 2, 1):].max()) == -1
+    dpre.fill_(3.0)
+    ops.pool_mean_bwd_pull(dagg, P, seg_ptr, small, dpre)
+    whole = small.ptr[1:].long() <= live_e // 2
+    assert bool(torch.isfinite(dpre).all())
+    if bool(whole.any()):
+        assert float((dpre[whole] - want[whole]).abs().max()) <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("m,n", [(512, 41), (37, 7), (300, 200)])
