@@ -164,6 +164,8 @@ class SageTrainEngine:
         self.lstm = model.aggregator == 'lstm'
         if self.lstm and unsup:
             raise NotImplementedError("engine: the lstm aggregator runs the supervised (fig2a) step only")
+        if overlap_gather not in (True, False, 'auto'):
+            raise ValueError("overlap_gather: True, False or 'auto'")
         if self.pool or self.lstm:
             overlap_gather = False    # the layer-0 aggregate needs this step's weights (pool Linear / W_ih)
         # Data parallel: the gradient all-reduce of step i is launched behind the backward's last
@@ -235,6 +237,11 @@ class SageTrainEngine:
         self.table = ops.new_relabel_table(self.graph.num_nodes, dev)
         # sample-buffer slots: batch i computes from one while the sampler fills the next; with
         # overlap_gather a third one, because then the sampler runs TWO batches ahead
+        if overlap_gather == 'auto':
+            # the side-stream gather costs a cross-stream hand-shake per step (~25 us) and pays when it
+            # hides more than that: Reddit's 602-float rows (340 MB of capacity per batch, 52 us) yes,
+            # PPI's 50-float rows (28 MB, 9 us) no — 0.187 against 0.158 ms per step
+            overlap_gather = 4 * model.layers[0].lin_l.weight.size(1) * edge_cap >= (128 << 20)
         self.overlap_gather = bool(overlap_gather)
         # Cross-stream events are the expensive part of pipelining on this platform (a wait and
         # a record on the main stream cost ~20 us per step, the sampler kernels beside the

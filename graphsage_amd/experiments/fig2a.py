@@ -119,7 +119,7 @@ def run(aggregator, dataset=None, num_epochs=None, batch_size=BATCH_SIZE, k1=K1,
         graph = train_loader.neighbor_sampler.graph
         engine = SageTrainEngine(model, train_loader.neighbor_sampler, graph.features(data), graph.labels(data),
                                  batch_size, lr=LEARNING_RATE,
-                                 overlap_gather=not os.environ.get('SAGE_FIG2A_SERIAL'))
+                                 overlap_gather=False if os.environ.get('SAGE_FIG2A_SERIAL') else 'auto')
         # (bench.py's headline schedule: the next batch's layer-0 gather beside this batch's step; through this
         # harness, 4 epochs at the Reddit shape: mean 0.269-0.278 against 0.282-0.287 ms per batch on one stream,
         # max 0.289 against 0.302.  The pooling engine ignores it.)

@@ -87,7 +87,7 @@ def _engine_for(trainer, unsup, explicit):
     return SageTrainEngine(trainer.model, sampler, graph.features(trainer.data), graph.labels(trainer.data),
                            trainer.train_loader.batch_size, lr=g['lr'], betas=g['betas'], eps=g['eps'],
                            weight_decay=g['weight_decay'], unsup=unsup,
-                           overlap_gather=True,
+                           overlap_gather='auto',
                            **_dp_engine())
 
 

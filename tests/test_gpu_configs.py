@@ -137,6 +137,9 @@ def test_ppi_shaped_multilabel_engine_steps_match_oracle(dev):
     engine = SageTrainEngine(model, NeighborSampler(data, FAN, seed=5), graph.features(data), graph.labels(data), B,
                              lr=1e-2, keep_grads=True)
     assert engine.multilabel and not engine.fused_logit
+    # 50-float rows: the schedule chosen by size is the serial one (the trainers / fig2a ask for 'auto')
+    assert not SageTrainEngine(copy.deepcopy(model), NeighborSampler(data, FAN, seed=5), graph.features(data),
+                               graph.labels(data), B, overlap_gather='auto').overlap_gather
     c0, r0, _ = csc.to_csc(data.edge_index.numpy(), n)
     ref = [{k: v.clone().requires_grad_(True) for k, v in p.items()} for p in layers]
     opt = torch.optim.Adam([v for p in ref for v in p.values()], lr=1e-2)
@@ -445,6 +448,9 @@ def test_reddit_shape_weight_gradient_slices_match_atomics(reddit, dev):
                                          graph.labels(data), B, lr=1e-3, keep_grads=keep)
     atom, sliced = mk(model_a, True), mk(model_b, False)
     assert atom.dw_parts is None and sliced.dw_parts is not None
+    # 602-float rows: the schedule chosen by size is the overlapped one
+    assert SageTrainEngine(copy.deepcopy(model_a), NeighborSampler.from_graph(graph, [25, 10], seed=0), graph.features(data),
+                           graph.labels(data), B, overlap_gather='auto').overlap_gather
     pool = torch.randperm(data.num_nodes, generator=torch.Generator().manual_seed(5))[:6 * B].to(dev)
     for s in range(6):
         seeds = pool[s * B:(s + 1) * B]
