@@ -224,13 +224,17 @@ def test_pipelined_eager_matches_serial_steps(dev, overlap):
 
 
 @pytest.mark.parametrize("aggregator,overlap", [("mean", False), ("mean", True), ("sum", True), ("max", False),
-                                                ("max", True), ("gcn", True), ("max_pool", False), ("lstm", False)])
+                                                ("max", True), ("gcn", True), ("max_pool", False), ("mean_pool", False),
+                                                ("lstm", False)])
 def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap, monkeypatch):
     """engine.evaluate() — the training pipeline run forward-only, one launch for the class-logit
     layer of the mean / sum step — predicts what GraphSAGE.inference + argmax predict
     (reference models/graphsage.py:51-68, fig2a/runners/graphsage_runners.py:57-66) on the same
     sampled batches; the tail that does not fill a batch included, and a training step afterwards
-    still finds its accumulation buffers zeroed."""
+    still finds its accumulation buffers zeroed.  Pooling aggregators: six batches of up to
+    1,344 sampled nodes against 3,000 nodes in the graph — the pass computes relu(pool(x)) once
+    over all nodes and the batches gather from it (engine._p_all), the reference side runs the
+    pool Linear per batch."""
     from graphsage_amd import settings
     from graphsage_amd.datasets import planted_partition
     from graphsage_amd.engine import SageTrainEngine
@@ -256,6 +260,7 @@ def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap, mo
     for _ in range(2):
         correct, count, pred = engine.evaluate(ids.to(dev), counter0=900, return_pred=True)
         assert int(count) == n_eval and pred.numel() == n_eval
+        assert (engine._p_all_buf is not None) == aggregator.endswith("_pool") and engine._p_all is None
         # the same batches through the separate kernels of forward() + torch.argmax
         want, margin = [], []
         padded = torch.cat([ids, ids[5 * B:5 * B + 1].expand(6 * B - n_eval)]).to(dev)
