@@ -137,10 +137,13 @@ def test_lstm_engine_padded_slot_split(dev, fanout, n_in, padsum, monkeypatch):
             pa.data.copy_(pb.data)          # same weights for the next batch (Adam ran on the engine only)
 
 
-@pytest.mark.parametrize("split", [False, True])
-def test_graph_replay_matches_eager_steps(dev, split, overlap=False):
+@pytest.mark.parametrize("split,aggregator", [(False, "mean"), (True, "mean"), (False, "max_pool"), (False, "mean_pool")])
+def test_graph_replay_matches_eager_steps(dev, split, aggregator, monkeypatch, overlap=False):
     """HIP-graph replay (device control block drives seeds / Philox counter / stamp) runs the
-    same steps as eager engine.step, including the wrap at the end of the seed pool."""
+    same steps as eager engine.step, including the wrap at the end of the seed pool.  Pooling
+    aggregators: with the per-source edge lists (scan included) captured behind the sampler."""
+    if aggregator.endswith("_pool"):
+        monkeypatch.setenv("SAGE_POOL_PULL_ALL", "1")
     from graphsage_amd.datasets import planted_partition
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
@@ -150,11 +153,12 @@ def test_graph_replay_matches_eager_steps(dev, split, overlap=False):
     B = 32
     graph = device_graph(data)
     torch.manual_seed(1)
-    model_a = GraphSAGE(24, 16, "mean", 2, 5).to(dev)
+    model_a = GraphSAGE(24, 16, aggregator, 2, 5).to(dev)
     model_b = copy.deepcopy(model_a)
     mk = lambda m, ov=False: SageTrainEngine(m, NeighborSampler(data, [4, 3], seed=9), graph.features(data),
                                              graph.labels(data), B, lr=1e-2, overlap_gather=ov)
     eager, graphed = mk(model_a), mk(model_b, overlap)
+    assert (graphed.rev is not None) == aggregator.endswith("_pool")
     pool = torch.randperm(2000, generator=torch.Generator().manual_seed(0))[:3 * B + 7].to(dev)  # 3 batches
     graphed.step(pool[:B], counter=1000)      # an eager step before capture (stamps already in use)
     eager.step(pool[:B], counter=1000)
