@@ -99,9 +99,14 @@ def test_step_matches_golden(dev, path):
                 np.testing.assert_allclose(get(m).detach().cpu().numpy(), g[f"a{i}_{k}"], rtol=1e-4, atol=1e-6)
 
 
-@pytest.mark.parametrize("agg", ["mean", "max", "gcn"])
-def test_engine_step_matches_golden(dev, agg):
-    """The static-shape engine (sampler + fused forward/backward + device Adam) on the golden batch."""
+@pytest.mark.parametrize("agg", ["mean", "max", "gcn", "max_pool", "max_pool/pull"])
+def test_engine_step_matches_golden(dev, agg, monkeypatch):
+    """The static-shape engine (sampler + fused forward/backward + device Adam) on the golden batch.
+    max_pool: layer 0's edge pass pushed from the targets (what a batch this small takes) and,
+    "/pull", pulled by the source rows from the per-source edge lists (what Reddit-sized batches take)."""
+    agg, _, pull = agg.partition("/")
+    if pull:
+        monkeypatch.setenv("SAGE_POOL_PULL_ALL", "1")
     from graphsage_amd.data import Data
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
@@ -118,16 +123,24 @@ def test_engine_step_matches_golden(dev, agg):
             m.lin_l.weight.copy_(torch.from_numpy(g[f"w{i}_lin_l"]))
             if agg != "gcn":
                 m.lin_r.weight.copy_(torch.from_numpy(g[f"w{i}_lin_r"]))
+            if agg == "max_pool":
+                m.pool.weight.copy_(torch.from_numpy(g[f"w{i}_pool_w"]))
+                m.pool.bias.copy_(torch.from_numpy(g[f"w{i}_pool_b"]))
     graph = device_graph(data)
     B = len(s["seeds"])
     engine = SageTrainEngine(model, NeighborSampler(data, s["fanout"].tolist(), seed=int(s["rng_seed"])),
                              graph.features(data), graph.labels(data), B, lr=float(g["lr"]), keep_grads=True)
+    assert (engine.rev is not None) == bool(pull)
     loss = engine.step(torch.from_numpy(s["seeds"]).to(dev), counter=int(s["counter"]))
     nn = int(engine.buf.state[0])
     assert engine.buf.node[:nn].cpu().numpy().tolist() == s["node"].tolist()
     np.testing.assert_allclose(float(loss), float(g["loss"]), rtol=1e-5)
     np.testing.assert_allclose(engine.act[-1]["y"][:B].cpu().numpy(), g["y_hat"], rtol=1e-4, atol=2e-5)
     for i, m in enumerate(model.layers):
+        if agg == "max_pool":
+            for k, q in (("pool_w", m.pool.weight), ("pool_b", m.pool.bias)):
+                np.testing.assert_allclose(engine.gviews[q].cpu().numpy(), g[f"g{i}_{k}"], rtol=1e-3, atol=1e-6)
+                np.testing.assert_allclose(q.detach().cpu().numpy(), g[f"a{i}_{k}"], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(engine.gviews[m.lin_l.weight].cpu().numpy(), g[f"g{i}_lin_l"], rtol=1e-3, atol=1e-6)
         np.testing.assert_allclose(m.lin_l.weight.detach().cpu().numpy(), g[f"a{i}_lin_l"], rtol=1e-4, atol=1e-6)
         if agg == "gcn":
