@@ -13,6 +13,8 @@
 //     (what autograd derives for the two Linears and the scatter; rows that only one seed writes
 //     are stored instead of added; max sends each column to the row that supplied it)
 //   forward only (sage_logit_layer_infer): the arg-max class of every seed row.
+//   The training step's common shape (H = 256, mean / sum / gcn, pre-activation rows) runs forward +
+//   backward with FOUR waves per seed (logit_fb4_kernel), everything else with one (logit_fwd_kernel).
 // The layer's weight gradients and the loss mean need every seed's dz: they ride as extra
 // workgroups in front of another launch's grid (skinny_dw.h; rowops.hip's normalise-backward pass
 // in the engine's step, or logit_bwd_dw_kernel below).
@@ -72,6 +74,29 @@ struct MaxOp {
   __device__ float neutral(float x) const { return x; }
 };
 __device__ inline float wave_total(float v) { return wave_reduce_dpp(v, SumOp{}); }
+// Sum over the 16 lanes of a row, in every lane of the row (the first four steps of the above).
+__device__ inline float row16_total(float v) {
+  auto step = [](float x, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v += step(v, std::integral_constant<int, 0xb1>{});      // quad_perm:[1,0,3,2]
+  v += step(v, std::integral_constant<int, 0x4e>{});      // quad_perm:[2,3,0,1]
+  v += step(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+  v += step(v, std::integral_constant<int, 0x140>{});     // row_mirror
+  return v;
+}
+// v_permlane32_swap / v_permlane16_swap (gfx950): lanes 32-63 (the odd 16-lane rows) of a change
+// places with lanes 0-31 (the even rows) of b — one VALU instruction, no LDS crossbar.  After it
+// a + b is, in the lower half (even rows), the sum of the old a over the lane pair, and in the
+// upper half (odd rows) the sum of the old b: one step of a transposing reduction.
+__device__ inline float swap32_sum(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float swap16_sum(float a, float b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 __device__ inline float wave_top(float v) { return wave_reduce_dpp(v, MaxOp{}); }
 __device__ inline float wave_max(float v) {
 #pragma unroll
@@ -548,6 +573,324 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
 }
 
 // NC = H / 64 (a lane owns columns lane + 64 k)
+// The training step's common case once more — H = 256, mean or sum, pre-activation rows, backward in
+// the same launch — with FOUR waves per seed and two seeds per workgroup (512 threads, 256
+// workgroups: one per CU).  The one-wave kernel above is a chain of latencies (25.6 us for 512
+// seeds, cycle stamps of scratch/logit_prof.hip: rows 8.3 us, products 4.7, softmax 1, the
+// backward's products 3, its scatter 7) on half of the CUs; here every link of the chain is a
+// quarter as long: a wave gathers and normalises every fourth row of its seed's segment, forms the
+// products of every fourth class (classes sub, sub + 4, ...) and the backward's partial d agg / d
+// root over the same classes, and scatters every fourth row.  The partial aggregates, the logits
+// and the partial row gradients cross the four waves through LDS (three barriers).
+constexpr int kFb4Block = 512;
+constexpr int kFb4H = 256;
+constexpr int kFb4Extra = 2 * (2 * 4 * kFb4H) + 2 * 64;      // floats of LDS behind the weights
+
+// GCN (layers/sage.py:114-117): the neighbour rows and ONE self-loop averaged for targets that have
+// neighbours, no root weight (w_r is not read for the products), the target's own row takes the
+// self-loop's share of d agg — as RED = 2 of logit_fwd_kernel.
+template <bool GCN>
+__global__ void __launch_bounds__(kFb4Block, 2)      // (two waves per SIMD: the register file is the wave's up to 256 VGPRs)
+logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
+                 const int64_t* __restrict__ src, int64_t m, int mean,
+                 const float* __restrict__ w_l, int64_t ld_wl, const float* __restrict__ w_r, int64_t ld_wr,
+                 int n, const int64_t* __restrict__ labels, const int64_t* __restrict__ label_rows,
+                 float grad_scale, float* __restrict__ agg, int64_t ld_agg, float* __restrict__ y, int64_t ld_y,
+                 float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
+                 float* __restrict__ row_loss, float* __restrict__ h_root, int64_t ld_h_root,
+                 float* __restrict__ dh, int64_t ld_dh, const int* __restrict__ writers) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
+  constexpr int H = kFb4H;
+  float* const part_a = wlds + static_cast<int64_t>(n) * 2 * H;      // [2 seeds][4 waves][H]
+  float* const part_r = part_a + 2 * 4 * H;
+  float* const zb = part_r + 2 * 4 * H;                               // [2 seeds][64]
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave);
+  const int sd = wave >> 2, sub = wave & 3;
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * 2 + sd;
+  const bool live = t < m;      // wave-uniform; every wave takes part in the staging and the barriers
+  auto sumsq = [](const float4& r) { return r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w; };
+  auto activate = [](float4& r, float ss) {      // relu(z / max(|z|, eps)) as in logit_fwd_kernel
+    const float inv = fminf(__builtin_amdgcn_rsqf(ss), 1.f / kNormEps);
+    r.x = fmaxf(r.x * inv, 0.f);
+    r.y = fmaxf(r.y * inv, 0.f);
+    r.z = fmaxf(r.z * inv, 0.f);
+    r.w = fmaxf(r.w * inv, 0.f);
+  };
+  LOGIT_STAMP(0, 0);
+  const int64_t tc = live ? t : m - 1;
+  const int64_t s0 = seg_ptr[tc];
+  const int64_t len = seg_ptr[tc + 1] - s0;
+  const int64_t lab_row = label_rows != nullptr ? label_rows[tc] : tc;
+  float4 root = reinterpret_cast<const float4*>(hrows + tc * ld_h)[lane];
+  int64_t my0 = 0;
+  if (lane < len) my0 = src[s0 + lane];
+  int solo0 = 0, solo_root = 0;
+  if (writers != nullptr) {
+    if (lane < len) solo0 = writers[my0] == 1 ? 1 : 0;
+    solo_root = writers[tc] == 1 ? 1 : 0;
+  }
+  // the weights: thread -> (row `wave` of a pass of 8 rows, float4 `lane` of the row); six passes
+  // (48 rows of each matrix) are requested here and stored once the rows are on their way
+  constexpr int kPasses = 6;
+  float4 vl[kPasses], vr[kPasses];
+#pragma unroll
+  for (int b = 0; b < kPasses; ++b) {
+    int c = b * 8 + wave;
+    if (c >= n) c = n - 1;
+    vl[b] = *reinterpret_cast<const float4*>(w_l + c * ld_wl + lane * 4);
+    vr[b] = *reinterpret_cast<const float4*>(w_r + c * ld_wr + lane * 4);
+  }
+  LOGIT_STAMP(0, 1);
+  const int64_t lab = labels[lab_row];
+  activate(root, wave_total(sumsq(root)));
+  if (live && sub == 0) reinterpret_cast<float4*>(h_root + t * ld_h_root)[lane] = root;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  // rows r0, r0 + 4, ... of a chunk of 64 edges, eight in flight at once (a fan-out of up to 32 in one round)
+  auto load_rows = [&](float4 (&x)[8], int64_t my, int r0, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = r0 + 4 * i;
+      if (r < chunk) x[i] = reinterpret_cast<const float4*>(hrows + readlane64(my, r) * ld_h)[lane];
+    }
+  };
+  auto add_rows = [&](float4 (&x)[8], int r0, int chunk) __attribute__((always_inline)) {
+    float ss[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss[i] = r0 + 4 * i < chunk ? wave_total(sumsq(x[i])) : 0.f;      // (wave-uniform test)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (r0 + 4 * i < chunk) {
+        activate(x[i], ss[i]);
+        acc.x += x[i].x;
+        acc.y += x[i].y;
+        acc.z += x[i].z;
+        acc.w += x[i].w;
+      }
+    }
+  };
+  float4 x[8];
+  const int chunk0 = !live ? 0 : (len < kWave ? static_cast<int>(len) : kWave);
+  load_rows(x, my0, sub, chunk0);
+  // (the first round of rows is requested: now the weights, which arrived before them)
+#pragma unroll
+  for (int b = 0; b < kPasses; ++b) {
+    const int c = b * 8 + wave;
+    if (c < n) {
+      float* row = wlds + static_cast<int64_t>(c) * 2 * H + lane * 4;
+      *reinterpret_cast<float4*>(row) = vl[b];
+      *reinterpret_cast<float4*>(row + H) = vr[b];
+    }
+  }
+  add_rows(x, sub, chunk0);
+  for (int r0 = sub + 32; r0 < chunk0; r0 += 32) {
+    load_rows(x, my0, r0, chunk0);
+    add_rows(x, r0, chunk0);
+  }
+  if (live) {
+    for (int64_t base = kWave; base < len; base += kWave) {
+      const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
+      int64_t my = 0;
+      if (lane < chunk) my = src[s0 + base + lane];
+      for (int r0 = sub; r0 < chunk; r0 += 32) {
+        load_rows(x, my, r0, chunk);
+        add_rows(x, r0, chunk);
+      }
+    }
+  }
+  for (int c0 = kPasses * 8; c0 < n; c0 += 8) {      // classes 48 .. 63
+    const int c = c0 + wave;
+    if (c < n) {
+      float* row = wlds + static_cast<int64_t>(c) * 2 * H + lane * 4;
+      *reinterpret_cast<float4*>(row) = *reinterpret_cast<const float4*>(w_l + c * ld_wl + lane * 4);
+      *reinterpret_cast<float4*>(row + H) = *reinterpret_cast<const float4*>(w_r + c * ld_wr + lane * 4);
+    }
+  }
+  LOGIT_STAMP(0, 2);
+  *reinterpret_cast<float4*>(part_a + (sd * 4 + sub) * H + 4 * lane) = acc;
+  __syncthreads();
+
+  LOGIT_STAMP(0, 3);
+  // the seed's aggregate (every wave of the seed adds the four parts up for itself)
+  float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float4 q = *reinterpret_cast<const float4*>(part_a + (sd * 4 + s) * H + 4 * lane);
+    a4.x += q.x;
+    a4.y += q.y;
+    a4.z += q.z;
+    a4.w += q.w;
+  }
+  if (GCN) {
+    if (len > 0) {
+      const float cnt = static_cast<float>(len) + 1.f;
+      a4.x = (a4.x + root.x) / cnt;
+      a4.y = (a4.y + root.y) / cnt;
+      a4.z = (a4.z + root.z) / cnt;
+      a4.w = (a4.w + root.w) / cnt;
+    }
+  } else if (mean) {
+    const float cnt = len > 0 ? static_cast<float>(len) : 1.f;
+    a4.x /= cnt;
+    a4.y /= cnt;
+    a4.z /= cnt;
+    a4.w /= cnt;
+  }
+  if (live && sub == 0) reinterpret_cast<float4*>(agg + t * ld_agg)[lane] = a4;
+  // z[c] for the classes c = sub + 4 j: every lane's share of the 16 products, summed over the 64
+  // lanes below
+  float p[16];
+#pragma unroll
+  for (int j0 = 0; j0 < 16; j0 += 8) {
+    float4 a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int c = sub + 4 * (j0 + j);
+      if (c >= n) c = n - 1;
+      const float4* wl = reinterpret_cast<const float4*>(wlds + static_cast<int64_t>(c) * 2 * H);
+      a[j] = wl[lane];
+      if (!GCN) b[j] = wl[H / 4 + lane];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float q = a4.x * a[j].x + a4.y * a[j].y + a4.z * a[j].z + a4.w * a[j].w;
+      if (!GCN) q += root.x * b[j].x + root.y * b[j].y + root.z * b[j].z + root.w * b[j].w;
+      p[j0 + j] = sub + 4 * (j0 + j) < n ? q : 0.f;
+    }
+  }
+  LOGIT_STAMP(0, 8);
+  // 16 values x 64 lanes -> 16 totals, on the VALU (47 ds_bpermute exchanges from eight waves queued
+  // on the CU's one LDS pipe for 4.5 us): two transposing steps across the half-waves and the
+  // 16-lane rows leave 4 values per lane (index 8 [lane & 32] + 4 [lane & 16] + j), which are summed
+  // over the row's 16 lanes by DPP
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p[j] = swap32_sum(p[j], p[j + 8]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p[j] = swap16_sum(p[j], p[j + 4]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) p[j] = row16_total(p[j]);
+  LOGIT_STAMP(0, 9);
+  if ((lane & 15) == 0) {
+    const int v0 = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) zb[sd * 64 + sub + 4 * (v0 + j)] = p[j];
+  }
+  __syncthreads();
+
+  LOGIT_STAMP(0, 4);
+  // normalise + cross entropy + d loss / d z, one class per lane (every wave of the seed for itself)
+  const bool has = lane < n;
+  const float zc = has ? zb[sd * 64 + lane] : 0.f;
+  const float ssz = wave_total(has ? zc * zc : 0.f);
+  const float denom = fmaxf(sqrtf(ssz), kNormEps);
+  const float inv = 1.f / denom;
+  const bool clamped = inv >= 1.f / kNormEps;
+  const float yv = zc / denom;
+  const float mx = wave_top(has ? yv : -INFINITY);
+  const float se = wave_total(has ? expf(yv - mx) : 0.f);
+  const float lse = mx + logf(se);
+  const float scale = grad_scale / static_cast<float>(m);
+  float g = has ? expf(yv - lse) : 0.f;
+  if (has && lane == lab) g -= 1.f;
+  g *= scale;
+  const float at_label = wave_total(has && lane == lab ? yv : 0.f);
+  const float dot = clamped ? 0.f : wave_total(has ? yv * g : 0.f);
+  const float dzv = has ? (g - yv * dot) * inv : 0.f;
+  if (live && sub == 0) {
+    if (lane == 0) {
+      if (inv_norm != nullptr) inv_norm[t] = inv;
+      row_loss[t] = (lab >= 0 && lab < n) ? lse - at_label : 0.f;
+    }
+    if (has) {
+      if (y != nullptr) y[t * ld_y + lane] = yv;
+      dz[t * ld_dz + lane] = dzv;
+    }
+  }
+
+  LOGIT_STAMP(0, 5);
+  // the backward's products over this wave's classes: lane l owns columns l + 64 k
+  float da[4], dr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) da[k] = dr[k] = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int c = sub + 4 * j;
+    if (c < n) {      // wave-uniform
+      const float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dzv), c));
+      const float* wl = wlds + static_cast<int64_t>(c) * 2 * H;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        da[k] += d * wl[lane + kWave * k];
+        if (!GCN) dr[k] += d * wl[H + lane + kWave * k];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    part_a[(sd * 4 + sub) * H + lane + kWave * k] = da[k];
+    part_r[(sd * 4 + sub) * H + lane + kWave * k] = dr[k];
+  }
+  __syncthreads();
+  LOGIT_STAMP(0, 6);
+  if (!live) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    da[k] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) da[k] += part_a[(sd * 4 + s) * H + lane + kWave * k];
+  }
+  if (GCN) {
+    if (len <= 0) return;
+    const float cnt = static_cast<float>(len) + 1.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) da[k] /= cnt;
+  }
+  if (sub == 0) {
+    float* rootp = dh + t * ld_dh;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float v = da[k];      // gcn: the self-loop's share
+      if (!GCN) {
+        v = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v += part_r[(sd * 4 + s) * H + lane + kWave * k];
+      }
+      if (solo_root) rootp[lane + kWave * k] = v;      // (wave-uniform)
+      else atomicAdd(rootp + lane + kWave * k, v);
+    }
+  }
+  if (len <= 0) return;
+  if (!GCN && mean) {
+    const float cnt = static_cast<float>(len);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) da[k] /= cnt;
+  }
+  for (int64_t base = 0; base < len; base += kWave) {
+    const int chunk = (len - base) < kWave ? static_cast<int>(len - base) : kWave;
+    int64_t my = my0;
+    int solo = solo0;
+    if (base > 0) {
+      my = 0;
+      solo = 0;
+      if (lane < chunk) {
+        my = src[s0 + base + lane];
+        if (writers != nullptr) solo = writers[my] == 1 ? 1 : 0;
+      }
+    }
+    for (int r = sub; r < chunk; r += 4) {
+      float* rowp = dh + readlane64(my, r) * ld_dh;
+      if (__builtin_amdgcn_readlane(solo, r)) {      // (wave-uniform)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rowp[lane + kWave * k] = da[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(rowp + lane + kWave * k, da[k]);
+      }
+    }
+  }
+  LOGIT_STAMP(0, 7);
+}
+
 template <int NC, bool FULL>      // FULL: h == 64 NC
 __device__ __forceinline__ void
 logit_bwd_body(const float* __restrict__ dz, int64_t ld_dz, const int64_t* __restrict__ seg_ptr,
@@ -735,6 +1078,29 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
   if (rc != SAGE_OK) return rc;
   const unsigned grid = static_cast<unsigned>(cdiv(m, kLogitWaves));
   const int mean = reduce == SAGE_REDUCE_MEAN ? 1 : 0;
+  // the training step's common case: four waves per seed (SAGE_LOGIT_ONE_WAVE=1: the general kernel)
+  static const bool one_wave = getenv("SAGE_LOGIT_ONE_WAVE") != nullptr;
+  const size_t lds4 = lds + kFb4Extra * sizeof(float);
+  if (!one_wave && dh != nullptr && pre && h == kFb4H &&
+      (reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_GCN) && pred == nullptr &&
+      dz != nullptr && agg != nullptr && labels != nullptr && row_loss != nullptr && h_root != nullptr && lds4 <= 160 * 1024) {
+    const unsigned grid4 = static_cast<unsigned>(cdiv(m, 2));
+    if (reduce == SAGE_REDUCE_GCN) {
+      const int rc4 = allow_lds(logit_fb4_kernel<true>, lds4, who);
+      if (rc4 != SAGE_OK) return rc4;
+      logit_fb4_kernel<true><<<grid4, kFb4Block, lds4, stream>>>(
+          h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
+          inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, dh, ld_dh, writers);
+    } else {
+      const int rc4 = allow_lds(logit_fb4_kernel<false>, lds4, who);
+      if (rc4 != SAGE_OK) return rc4;
+      logit_fb4_kernel<false><<<grid4, kFb4Block, lds4, stream>>>(
+          h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
+          inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, dh, ld_dh, writers);
+    }
+    SAGE_CHECK_LAUNCH("logit_fb4_kernel");
+    return SAGE_OK;
+  }
 #define SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, RED)                                                               \
   do {                                                                                                      \
     const int rc2 = allow_lds(logit_fwd_kernel<NV, FULL, PRE, BWD, RED>, lds, who);                         \

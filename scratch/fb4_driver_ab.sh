@@ -1,0 +1,8 @@
+# same-box A/B of the driver-style short window (--steps 20 --warmup 5), four waves per seed (default) against one
+set -e
+for rep in 1 2 3; do
+  for v in "" 1; do
+    if [ -n "$v" ]; then export SAGE_LOGIT_ONE_WAVE=1; else unset SAGE_LOGIT_ONE_WAVE; fi
+    timeout -k 10 200 python bench.py --cpu-steps 0 --no-variant --no-probe --steps 20 --warmup 5 2>/dev/null | python3 -c "import sys,json; d=json.loads([l for l in sys.stdin if l.startswith('{')][0]); print('driver-style ONE_WAVE=%s' % '$v', d['ms_per_step'])"
+  done
+done

@@ -36,7 +36,10 @@ int main() {
   const bool pre = getenv("PRE") != nullptr;      // PRE=1: the rows are pre-activation rows, normalised on their way in
   auto fwd = [&]() { return sage_logit_layer_fwd(dh_, H, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dlab, nullptr, 1.f, agg, H, y, 64, inv, dz, 64, rl, pre ? hroot : nullptr, H, nullptr); };
   auto bwd = [&]() { return sage_logit_layer_bwd(dz, 64, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dgrad, H, rl, loss, nullptr); };
-  auto fb = [&]() { return sage_logit_layer_fwd_bwd(dh_, H, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dlab, nullptr, 1.f, agg, H, y, 64, inv, dz, 64, rl, pre ? hroot : nullptr, H, dgrad, H, nullptr); };
+  int* wr; CK(hipMalloc(&wr, (size_t)T * 4));
+  SK(sage_count_row_writers(dseg, dsrc, M, (sage_i64)M * K, wr, T, nullptr));
+  const bool solo = getenv("SOLO") != nullptr;    // SOLO=1: rows with one writer are stored (dgrad is not re-zeroed: timing only)
+  auto fb = [&]() { return sage_logit_layer_fwd_bwd(dh_, H, dseg, dsrc, M, H, SAGE_REDUCE_MEAN, dw, LDW, dw + (size_t)N * LDW, LDW, N, dlab, nullptr, 1.f, agg, H, y, 64, inv, dz, 64, rl, pre ? hroot : nullptr, H, dgrad, H, solo ? wr : nullptr, nullptr); };
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   float ms;
   for (int rep = 0; rep < 2; ++rep) {
@@ -52,7 +55,7 @@ int main() {
   {
     unsigned long long s2[2][16];
     CK(hipMemcpyFromSymbol(s2, HIP_SYMBOL(sage::g_logit_prof), sizeof(s2)));
-    printf("fwd+bwd stamps (x10 ns): "); for (int i = 1; i <= 7; ++i) printf("%lld ", (long long)(s2[0][i] - s2[0][0])); printf("\n");
+    printf("fwd+bwd stamps (x10 ns): "); for (int i = 1; i <= 9; ++i) printf("%lld ", (long long)(s2[0][i] - s2[0][0])); printf("\n");
     for (int i = 0; i < 3; ++i) { SK(fwd()); SK(bwd()); }
   }
   unsigned long long st[2][16];

@@ -867,7 +867,7 @@ def test_logit_layer_max_reduce_matches_torch(dev, h, n, pre, reduce):
 
 
 @pytest.mark.parametrize("reduce,h,n", [("mean", 256, 41), ("sum", 64, 7), ("mean", 512, 40), ("mean", 36, 5),
-                                        ("mean", 1024, 10)])
+                                        ("mean", 1024, 10), ("sum", 256, 64), ("mean", 256, 3)])
 def test_logit_layer_on_preactivation_rows(dev, reduce, h, n):
     """h_root given: the kernel reads the previous layer's PRE-activation rows z and takes every
     row through relu(normalize(.)) itself — against sage_l2norm_relu_fwd followed by the plain
