@@ -403,17 +403,20 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       for (int j = 0; j < 8; ++j) p[c0 + j] = 0.f;
     }
   }
+  // (on the VALU since the end of round 3: the 63 ds_bpermute exchanges of the butterfly queue on the
+  // CU's one LDS pipe behind the other waves' — 4.5 us for 47 of them from eight waves in
+  // logit_fb4_kernel.  Two transposing steps across the half-waves and the 16-lane rows
+  // (v_permlane32_swap / v_permlane16_swap) leave 16 values per lane, DPP sums them over the row in
+  // every lane of it, and lane l picks the one with index l & 15.)
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const bool up = (lane & o) != 0;
+  for (int j = 0; j < 32; ++j) p[j] = swap32_sum(p[j], p[j + 32]);
 #pragma unroll
-    for (int j = 0; j < o; ++j) {
-      const float send = up ? p[j] : p[j + o];
-      const float keep = up ? p[j + o] : p[j];
-      p[j] = keep + __shfl_xor(send, o);
-    }
-  }
-  const float zc = p[0];
+  for (int j = 0; j < 16; ++j) p[j] = swap16_sum(p[j], p[j + 16]);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) p[j] = row16_total(p[j]);
+  float zc = p[0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) zc = (lane & 15) == j ? p[j] : zc;
   LOGIT_STAMP(0, 5);
   // normalise + cross entropy + d loss / d z on the n <= 64 values, one per lane (the formulas of
   // logits_xent_fused_kernel, rowops.hip)
