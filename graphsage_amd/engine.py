@@ -408,6 +408,7 @@ class SageTrainEngine:
         # the sampler's stream more than the step gains; tests).
         self.rev = None
         self._p_all = None          # evaluate(): relu(pool(x)) over all nodes while a pass runs
+        self._eval_pass = False     # evaluate(): the sampler's tape without the helpers of the backward
         self._p_all_buf = None
         a0 = self.act[0]
         if (self.pool and (a0['t_cap'] >= 4096 or os.environ.get('SAGE_POOL_PULL_ALL')) and a0['t_cap'] < 2 ** 23
@@ -543,8 +544,8 @@ class SageTrainEngine:
         args[10] = self._stamp
         _lib.check(fn(*args), name)
         _lib.check(acc[0](*acc[1]), acc[2])      # state_sum += this batch's sizes, same stream
-        if rest:
-            _lib.replay(rest)                    # (the class-logit layer's writer counts)
+        if rest and not self._eval_pass:
+            _lib.replay(rest)                    # (the backward's helpers: writer counts, per-source edge lists)
 
     def _count_writers(self, slot):
         """Behind the sampler, on its stream: how many seed waves will add into each row of the
@@ -1392,6 +1393,7 @@ class SageTrainEngine:
                 self._p_all_buf = torch.empty((n_nodes, (fin + 15) // 16 * 16), dtype=torch.float32, device=self.dev)[:, :fin]
             ops.pool_linear_fwd(self.features, layer.pool.weight, layer.pool.bias, m=n_nodes, out=self._p_all_buf)
             self._p_all = self._p_all_buf
+        self._eval_pass = True
         try:
             for b in range(min(d, nb)):
                 self.prefetch(padded[b * B:(b + 1) * B], counter0 + b)
@@ -1401,6 +1403,7 @@ class SageTrainEngine:
                                     infer_pred=pred_all[b * B * width:(b + 1) * B * width])
         finally:
             self._p_all = None
+            self._eval_pass = False
         if self.multilabel:      # (tp, fp, fn) over the real seeds: micro-F1 = 2 tp / (2 tp + fp + fn)
             tp, fp, fn = pred_all.view(-1, 3)[:n].sum(dim=0).view(3, 1).unbind(0)
             return tp, fp, fn
