@@ -623,7 +623,7 @@ adam_parts4_kernel(float4* __restrict__ param, float4* __restrict__ grad, float4
     g4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto add = [&](const float4& a) { g4.x += a.x; g4.y += a.y; g4.z += a.z; g4.w += a.w; };
     int sidx = 0;
-    for (; sidx + 4 <= parts; sidx += 4) {      // four slices in flight
+    for (; sidx + 4 <= parts; sidx += 4) {      // four slices in flight (all of them at once, clamped: 11.0 against 9.1 us)
       const float4 a0 = wp[(sidx + 0) * stride4], a1 = wp[(sidx + 1) * stride4], a2 = wp[(sidx + 2) * stride4],
                    a3 = wp[(sidx + 3) * stride4];
       add(a0); add(a1); add(a2); add(a3);
