@@ -417,6 +417,13 @@ class SageTrainEngine:
             self.rev = [ops.ReverseEdges(a0['s_cap'], edge_cap, dev) for _ in range(self.nslots)]
             if self.reduce == 'max':
                 a0['arg8'] = torch.zeros((a0['t_cap'], (a0['fin'] + 15) // 16 * 16), dtype=torch.uint8, device=dev)
+        # mean_pool, the layers above layer 0 (the B seeds' segments): the same pulled pass instead of
+        # the all-atomic one (17 us -> 5 at the Reddit shape), lists per layer and slot.  Not for max
+        # there: its pushed pass sends one value per (seed, column), 5 us.
+        self.rev_up = None
+        if self.rev is not None and self.reduce == 'mean' and self.L >= 2 and not os.environ.get('SAGE_NO_POOL_PULL_UP'):
+            self.rev_up = {i: [ops.ReverseEdges(self.act[i]['s_cap'], self.act[i]['t_cap'] * max(fan), dev)
+                               for _ in range(self.nslots)] for i in range(1, self.L)}
         if self.unsup:
             self.pos_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
             self.neg_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
@@ -556,6 +563,10 @@ class SageTrainEngine:
         if self.rev is not None:      # (pooling) layer 0's edges per source row, for its backward's edge pass
             a, buf = self.act[0], self.bufs[slot]
             self.rev[slot].build(buf.seg_ptr, buf.src, a['t_cap'], num_targets_dev=self.n_dev[slot][a['hop']])
+            if self.rev_up is not None:
+                for i, revs in self.rev_up.items():
+                    a = self.act[i]
+                    revs[slot].build(buf.seg_ptr, buf.src, a['t_cap'], num_targets_dev=self.n_dev[slot][a['hop']])
 
     def _next_stamp(self, stream=None):
         """Stamps of the relabel table must grow (sage_hip.h); when the 32-bit range is used up,
@@ -680,7 +691,7 @@ class SageTrainEngine:
         # layer 0 stores every row itself)
         ops.pool_linear_fwd(x, layer.pool.weight, layer.pool.bias, m=a['s_cap'],
                             m_dev=self.n_dev[slot][a['src_hop']], rows=node_map, out=a['P'],
-                            dpre=None if (i == 0 and self.rev is not None) else a['dpre'])
+                            dpre=None if ((i == 0 and self.rev is not None) or (i > 0 and self.rev_up is not None)) else a['dpre'])
 
     @staticmethod
     def _lstm_blocks(fdim):
@@ -994,6 +1005,8 @@ class SageTrainEngine:
                 lib.pool_max_bwd_pull(a['dagg'], a['arg8'], self.rev[slot], a['dpre'], num_sources_dev=s_dev)
             else:
                 lib.pool_mean_bwd_pull(a['dagg'], a['P'], buf.seg_ptr, self.rev[slot], a['dpre'], num_sources_dev=s_dev)
+        elif i > 0 and self.rev_up is not None:
+            lib.pool_mean_bwd_pull(a['dagg'], a['P'], buf.seg_ptr, self.rev_up[i][slot], a['dpre'], num_sources_dev=s_dev)
         elif self.reduce == 'max':
             agg_i = self.agg0[slot] if i == 0 else a['agg']
             # (the bias gradient = column sums of d pre for max as for mean: the weight-gradient
