@@ -97,6 +97,9 @@ SIGNATURES = {
     "sage_logit_layer_fwd_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
                                          _P, _P, c_float, _P, c_int64, _P, c_int64, _P, _P, c_int64, _P, _P, c_int64,
                                          _P, c_int64, _P, _P]),
+    "sage_logit_layer_pool_fwd_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P,
+                                              c_int64, c_int, _P, _P, c_float, _P, c_int64, _P, c_int64, _P, _P, c_int64,
+                                              _P, _P, c_int64, _P, c_int64, _P, _P]),
     "sage_count_row_writers": (c_int, [_P, _P, c_int64, c_int64, _P, c_int64, _P]),
     "sage_logit_layer_bwd": (c_int, [_P, c_int64, _P, _P, c_int64, c_int, c_int, _P, c_int64, _P, c_int64, c_int,
                                      _P, c_int64, _P, _P, _P]),

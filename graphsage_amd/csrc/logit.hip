@@ -183,12 +183,20 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
                  float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
                  float* __restrict__ row_loss, float* __restrict__ h_root, int64_t ld_h_root,
                  int64_t* __restrict__ pred, float* __restrict__ dh, int64_t ld_dh,
-                 const int* __restrict__ writers) {
+                 const int* __restrict__ writers, const float* __restrict__ prows, int64_t ld_p,
+                 float* __restrict__ dnb, int64_t ld_dnb) {
+  // prows != NULL (the pooling aggregators' last layer, layers/sage.py:201-210; never with PRE): the
+  // NEIGHBOUR rows come from prows = relu(pool(h)) while the root row stays hrows[t], and the
+  // backward sends the neighbours' share to dnb = the gradient of pool(h) — through the relu: a
+  // row's element takes it where prows is positive (max: where the maximum is) — and the root's to dh.
   // Forward-only callers (sage_logit_layer_infer) pass labels = agg = dz = row_loss = NULL and
   // take y and / or pred (the arg-max class of each seed row); every one of these tests is
   // wave-uniform.
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   constexpr bool MAX = RED == 1, GCN = RED == 2;
+  const bool pool = prows != nullptr;                  // (uniform)
+  const float* const nbase = pool ? prows : hrows;     // where the neighbour rows are read
+  const int64_t ld_n = pool ? ld_p : ld_h;
   const int lane = threadIdx.x & (kWave - 1);
   const int64_t t = static_cast<int64_t>(blockIdx.x) * kLogitWaves + threadIdx.x / kWave;
   const bool live = t < m;      // wave-uniform; every wave takes part in the staging and the barrier
@@ -247,8 +255,10 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   int solo0 = 0, solo_root = 0;
   if constexpr (BWD) {
     if (writers != nullptr) {
-      if (lane < len) solo0 = writers[my0] == 1 ? 1 : 0;           // needs my0
-      solo_root = writers[tc] == 1 ? 1 : 0;
+      // (pool: the two sinks are different buffers — a seed's own row of dh has that seed as its one
+      // writer, a row of dnb the row's in-edges: the count less the seed's own entry)
+      if (lane < len) solo0 = writers[my0] - ((pool && my0 < m) ? 1 : 0) == 1 ? 1 : 0;           // needs my0
+      solo_root = (pool || writers[tc] == 1) ? 1 : 0;
     }
   }
   WeightStage st;                                      // requested behind it, stored while the rows travel
@@ -280,7 +290,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
 #pragma unroll
         for (int r = 0; r < kRowsInFlight; ++r) {
           if (r0 + r < chunk) {
-            const float4* rowp = reinterpret_cast<const float4*>(hrows + readlane64(my, r0 + r) * ld_h);
+            const float4* rowp = reinterpret_cast<const float4*>(nbase + readlane64(my, r0 + r) * ld_n);
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
               if (in_row(v)) x[r][v] = rowp[lane + kWave * v];
@@ -488,11 +498,13 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
         if (solo_root) rootp[j] = dr[j];      // (wave-uniform)
         else atomicAdd(rootp + j, dr[j]);
       }
+      const float mxv[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (arg[v][j] >= 0) {
           const int64_t row = src[s0 + arg[v][j]];
-          atomicAdd(dh + row * ld_dh + 4 * (lane + kWave * v) + j, da[j]);
+          if (!pool) atomicAdd(dh + row * ld_dh + 4 * (lane + kWave * v) + j, da[j]);
+          else if (mxv[j] > 0.f) atomicAdd(dnb + row * ld_dnb + 4 * (lane + kWave * v) + j, da[j]);
         }
       }
     }
@@ -553,8 +565,42 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
         solo = 0;
         if (lane < chunk) {
           my = src[s0 + base + lane];
-          if (writers != nullptr) solo = writers[my] == 1 ? 1 : 0;
+          if (writers != nullptr) solo = writers[my] - ((pool && my < m) ? 1 : 0) == 1 ? 1 : 0;
         }
+      }
+      if (pool) {
+        // through the relu of the rows that were read: their values once more (out of L2), a batch
+        // of rows requested together so that the segment is not one round trip per row
+        constexpr int kBatch = 8 / NV;
+        for (int r0 = 0; r0 < chunk; r0 += kBatch) {
+          float pv[kBatch][NC];
+#pragma unroll
+          for (int i = 0; i < kBatch; ++i) {
+            if (r0 + i < chunk) {
+              const float* pr = nbase + readlane64(my, r0 + i) * ld_n;
+#pragma unroll
+              for (int k = 0; k < NC; ++k) {
+                if (FULL || lane + kWave * k < h) pv[i][k] = pr[lane + kWave * k];
+              }
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < kBatch; ++i) {
+            if (r0 + i < chunk) {
+              float* rowp = dnb + readlane64(my, r0 + i) * ld_dnb;
+              const bool one = __builtin_amdgcn_readlane(solo, r0 + i) != 0;      // (wave-uniform)
+#pragma unroll
+              for (int k = 0; k < NC; ++k) {
+                if (FULL || lane + kWave * k < h) {
+                  const float v = pv[i][k] > 0.f ? da[k] : 0.f;
+                  if (one) rowp[lane + kWave * k] = v;
+                  else if (v != 0.f) atomicAdd(rowp + lane + kWave * k, v);
+                }
+              }
+            }
+          }
+        }
+        continue;
       }
       for (int r = 0; r < chunk; ++r) {
         float* rowp = dh + readlane64(my, r) * ld_dh;
@@ -592,7 +638,10 @@ constexpr int kFb4Extra = 2 * (2 * 4 * kFb4H) + 2 * 64;      // floats of LDS be
 // GCN (layers/sage.py:114-117): the neighbour rows and ONE self-loop averaged for targets that have
 // neighbours, no root weight (w_r is not read for the products), the target's own row takes the
 // self-loop's share of d agg — as RED = 2 of logit_fwd_kernel.
-template <bool GCN>
+// POOL (the pooling aggregators' last layer, mean; as `prows` of logit_fwd_kernel): rows as they are
+// (no normalisation on the way in), the neighbour rows from prows = relu(pool(h)), their share of the
+// backward through the relu into dnb, the root's into dh (stored: its one writer).
+template <bool GCN, bool POOL = false>
 __global__ void __launch_bounds__(kFb4Block, 2)      // (two waves per SIMD: the register file is the wave's up to 256 VGPRs)
 logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
                  const int64_t* __restrict__ src, int64_t m, int mean,
@@ -601,9 +650,14 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
                  float grad_scale, float* __restrict__ agg, int64_t ld_agg, float* __restrict__ y, int64_t ld_y,
                  float* __restrict__ inv_norm, float* __restrict__ dz, int64_t ld_dz,
                  float* __restrict__ row_loss, float* __restrict__ h_root, int64_t ld_h_root,
-                 float* __restrict__ dh, int64_t ld_dh, const int* __restrict__ writers) {
+                 float* __restrict__ dh, int64_t ld_dh, const int* __restrict__ writers,
+                 const float* __restrict__ prows, int64_t ld_p, float* __restrict__ dnb, int64_t ld_dnb) {
   extern __shared__ __attribute__((aligned(16))) float wlds[];
   constexpr int H = kFb4H;
+  const float* const nbase = POOL ? prows : hrows;
+  const int64_t ld_n = POOL ? ld_p : ld_h;
+  float* const nsink = POOL ? dnb : dh;
+  const int64_t ld_ns = POOL ? ld_dnb : ld_dh;
   float* const part_a = wlds + static_cast<int64_t>(n) * 2 * H;      // [2 seeds][4 waves][H]
   float* const part_r = part_a + 2 * 4 * H;
   float* const zb = part_r + 2 * 4 * H;                               // [2 seeds][64]
@@ -630,8 +684,8 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   if (lane < len) my0 = src[s0 + lane];
   int solo0 = 0, solo_root = 0;
   if (writers != nullptr) {
-    if (lane < len) solo0 = writers[my0] == 1 ? 1 : 0;
-    solo_root = writers[tc] == 1 ? 1 : 0;
+    if (lane < len) solo0 = writers[my0] - ((POOL && my0 < m) ? 1 : 0) == 1 ? 1 : 0;
+    solo_root = (POOL || writers[tc] == 1) ? 1 : 0;
   }
   // the weights: thread -> (row `wave` of a pass of 8 rows, float4 `lane` of the row); six passes
   // (48 rows of each matrix) are requested here and stored once the rows are on their way
@@ -646,25 +700,29 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   }
   LOGIT_STAMP(0, 1);
   const int64_t lab = labels[lab_row];
-  activate(root, wave_total(sumsq(root)));
-  if (live && sub == 0) reinterpret_cast<float4*>(h_root + t * ld_h_root)[lane] = root;
+  if (!POOL) {
+    activate(root, wave_total(sumsq(root)));
+    if (live && sub == 0) reinterpret_cast<float4*>(h_root + t * ld_h_root)[lane] = root;
+  }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   // rows r0, r0 + 4, ... of a chunk of 64 edges, eight in flight at once (a fan-out of up to 32 in one round)
   auto load_rows = [&](float4 (&x)[8], int64_t my, int r0, int chunk) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = r0 + 4 * i;
-      if (r < chunk) x[i] = reinterpret_cast<const float4*>(hrows + readlane64(my, r) * ld_h)[lane];
+      if (r < chunk) x[i] = reinterpret_cast<const float4*>(nbase + readlane64(my, r) * ld_n)[lane];
     }
   };
   auto add_rows = [&](float4 (&x)[8], int r0, int chunk) __attribute__((always_inline)) {
     float ss[8];
+    if (!POOL) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ss[i] = r0 + 4 * i < chunk ? wave_total(sumsq(x[i])) : 0.f;      // (wave-uniform test)
+      for (int i = 0; i < 8; ++i) ss[i] = r0 + 4 * i < chunk ? wave_total(sumsq(x[i])) : 0.f;      // (wave-uniform test)
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (r0 + 4 * i < chunk) {
-        activate(x[i], ss[i]);
+        if (!POOL) activate(x[i], ss[i]);
         acc.x += x[i].x;
         acc.y += x[i].y;
         acc.z += x[i].z;
@@ -877,8 +935,37 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       solo = 0;
       if (lane < chunk) {
         my = src[s0 + base + lane];
-        if (writers != nullptr) solo = writers[my] == 1 ? 1 : 0;
+        if (writers != nullptr) solo = writers[my] - ((POOL && my < m) ? 1 : 0) == 1 ? 1 : 0;
       }
+    }
+    if (POOL) {
+      // through the relu of the rows that were read: their values once more (out of L2), eight rows of
+      // this wave's share requested together
+      for (int r0 = sub; r0 < chunk; r0 += 32) {
+        float pv[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (r0 + 4 * i < chunk) {
+            const float* pr = nbase + readlane64(my, r0 + 4 * i) * ld_n;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pv[i][k] = pr[lane + kWave * k];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (r0 + 4 * i < chunk) {
+            float* rowp = nsink + readlane64(my, r0 + 4 * i) * ld_ns;
+            const bool one = __builtin_amdgcn_readlane(solo, r0 + 4 * i) != 0;      // (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float v = pv[i][k] > 0.f ? da[k] : 0.f;
+              if (one) rowp[lane + kWave * k] = v;
+              else if (v != 0.f) atomicAdd(rowp + lane + kWave * k, v);
+            }
+          }
+        }
+      }
+      continue;
     }
     for (int r = sub; r < chunk; r += 4) {
       float* rowp = dh + readlane64(my, r) * ld_dh;
@@ -1074,7 +1161,8 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
                      sage_i64 m, int h, int reduce, const float* w_l, sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n,
                      const sage_i64* labels, const sage_i64* label_rows, float grad_scale, float* agg, sage_i64 ld_agg,
                      float* y, sage_i64 ld_y, float* inv_norm, float* dz, sage_i64 ld_dz, float* row_loss, float* h_root,
-                     sage_i64 ld_h_root, sage_i64* pred, float* dh, sage_i64 ld_dh, const int* writers, hipStream_t stream) {
+                     sage_i64 ld_h_root, sage_i64* pred, float* dh, sage_i64 ld_dh, const int* writers, hipStream_t stream,
+                     const float* prows = nullptr, sage_i64 ld_p = 0, float* dnb = nullptr, sage_i64 ld_dnb = 0) {
   size_t lds = 0;
   // (max: its backward needs the arg-max of every column, which only lives in the forward's registers)
   const int rc = check_common(who, m, h, n, reduce, w_l, ld_wl, w_r, ld_wr, &lds, dz == nullptr || dh != nullptr);
@@ -1084,7 +1172,7 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
   // the training step's common case: four waves per seed (SAGE_LOGIT_ONE_WAVE=1: the general kernel)
   static const bool one_wave = getenv("SAGE_LOGIT_ONE_WAVE") != nullptr;
   const size_t lds4 = lds + kFb4Extra * sizeof(float);
-  if (!one_wave && dh != nullptr && pre && h == kFb4H &&
+  if (!one_wave && prows == nullptr && dh != nullptr && pre && h == kFb4H &&
       (reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_GCN) && pred == nullptr &&
       dz != nullptr && agg != nullptr && labels != nullptr && row_loss != nullptr && h_root != nullptr && lds4 <= 160 * 1024) {
     const unsigned grid4 = static_cast<unsigned>(cdiv(m, 2));
@@ -1093,15 +1181,26 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
       if (rc4 != SAGE_OK) return rc4;
       logit_fb4_kernel<true><<<grid4, kFb4Block, lds4, stream>>>(
           h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
-          inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, dh, ld_dh, writers);
+          inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, dh, ld_dh, writers, nullptr, 0, nullptr, 0);
     } else {
       const int rc4 = allow_lds(logit_fb4_kernel<false>, lds4, who);
       if (rc4 != SAGE_OK) return rc4;
       logit_fb4_kernel<false><<<grid4, kFb4Block, lds4, stream>>>(
           h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
-          inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, dh, ld_dh, writers);
+          inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, dh, ld_dh, writers, nullptr, 0, nullptr, 0);
     }
     SAGE_CHECK_LAUNCH("logit_fb4_kernel");
+    return SAGE_OK;
+  }
+  // ... and the pooling aggregators' last layer with the mean (sage_logit_layer_pool_fwd_bwd)
+  if (!one_wave && prows != nullptr && dnb != nullptr && dh != nullptr && !pre && h == kFb4H && reduce == SAGE_REDUCE_MEAN &&
+      pred == nullptr && dz != nullptr && agg != nullptr && labels != nullptr && row_loss != nullptr && lds4 <= 160 * 1024) {
+    const int rc4 = allow_lds(logit_fb4_kernel<false, true>, lds4, who);
+    if (rc4 != SAGE_OK) return rc4;
+    logit_fb4_kernel<false, true><<<static_cast<unsigned>(cdiv(m, 2)), kFb4Block, lds4, stream>>>(
+        h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
+        inv_norm, dz, ld_dz, row_loss, nullptr, 0, dh, ld_dh, writers, prows, ld_p, dnb, ld_dnb);
+    SAGE_CHECK_LAUNCH("logit_fb4_kernel(pool)");
     return SAGE_OK;
   }
 #define SAGE_LOGIT_FWD_Q(NV, FULL, PRE, BWD, RED)                                                               \
@@ -1110,7 +1209,7 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
     if (rc2 != SAGE_OK) return rc2;                                                                         \
     logit_fwd_kernel<NV, FULL, PRE, BWD, RED><<<grid, kLogitBlock, lds, stream>>>(                          \
         h_rows, ld_h, seg_ptr, src, m, h, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, \
-        ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, pred, dh, ld_dh, writers);                  \
+        ld_y, inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, pred, dh, ld_dh, writers, prows, ld_p, dnb, ld_dnb); \
   } while (0)
 #define SAGE_LOGIT_FWD_P(NV, FULL, PRE, BWD)                                                                    \
   do {                                                                                                      \
@@ -1179,6 +1278,28 @@ extern "C" int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, cons
   return launch_logit_fwd("sage_logit_layer_fwd_bwd", h_root != nullptr, h_rows, ld_h, seg_ptr, src, m, h, reduce, w_l, ld_wl,
                           w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y, inv_norm, dz, ld_dz, row_loss,
                           h_root, ld_h_root, nullptr, dh, ld_dh, writers, static_cast<hipStream_t>(stream_));
+}
+
+extern "C" int sage_logit_layer_pool_fwd_bwd(const float* h_rows, sage_i64 ld_h, const float* p_rows, sage_i64 ld_p,
+                                             const sage_i64* seg_ptr, const sage_i64* src, sage_i64 m, int h, int reduce,
+                                             const float* w_l, sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n,
+                                             const sage_i64* labels, const sage_i64* label_rows, float grad_scale,
+                                             float* agg, sage_i64 ld_agg, float* y, sage_i64 ld_y, float* inv_norm,
+                                             float* dz, sage_i64 ld_dz, float* row_loss, float* dh, sage_i64 ld_dh,
+                                             float* dpre, sage_i64 ld_dpre, const int* writers, void* stream_) {
+  SAGE_REQUIRE(h_rows && p_rows && seg_ptr && src && labels && agg && dz && row_loss && dh && dpre, SAGE_EINVAL,
+               "sage_logit_layer_pool_fwd_bwd: NULL pointer argument");
+  SAGE_REQUIRE(reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_MAX, SAGE_EINVAL,
+               "sage_logit_layer_pool_fwd_bwd: reduce must be mean or max (mean_pool / max_pool)");
+  SAGE_REQUIRE(ld_h >= h && ld_h % 4 == 0 && vec16(h_rows) && ld_p >= h && ld_p % 4 == 0 && vec16(p_rows) && ld_agg >= h &&
+                   ld_agg % 4 == 0 && vec16(agg) && ld_dz >= n && (y == nullptr || ld_y >= n) && ld_dh >= h && ld_dpre >= h,
+               SAGE_EINVAL,
+               "sage_logit_layer_pool_fwd_bwd: rows of h / p / agg must be 16-byte aligned and at least h wide, ld_dz / ld_y >= n");
+  SAGE_REQUIRE(dh != h_rows && dh != agg && dpre != p_rows && dpre != agg && dpre != dh, SAGE_EINVAL,
+               "sage_logit_layer_pool_fwd_bwd: a gradient buffer aliases an input or the other one");
+  return launch_logit_fwd("sage_logit_layer_pool_fwd_bwd", false, h_rows, ld_h, seg_ptr, src, m, h, reduce, w_l, ld_wl, w_r, ld_wr,
+                          n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y, inv_norm, dz, ld_dz, row_loss, nullptr, 0,
+                          nullptr, dh, ld_dh, writers, static_cast<hipStream_t>(stream_), p_rows, ld_p, dpre, ld_dpre);
 }
 
 namespace {

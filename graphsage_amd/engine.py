@@ -211,6 +211,16 @@ class SageTrainEngine:
         # loss mean ride in front of the hidden layer's normalise-backward pass
         # (sage_l2norm_relu_bwd_z_dw).  SAGE_NO_LOGIT_FWDBWD=1: forward and backward launches apart.
         self.logit_fwdbwd = self.prenorm and self.fused_logit_dw and not os.environ.get('SAGE_NO_LOGIT_FWDBWD')
+        # The pooling aggregators' last layer the same way (sage_logit_layer_pool_fwd_bwd: neighbour rows
+        # from relu(pool(h)), the root row from h, the neighbours' share of the input gradient sent
+        # through the relu straight into the gradient of pool(h)): one launch instead of gather /
+        # contraction / loss / loss mean / d-input pair / edge pass; the layer's weight gradients and
+        # the loss mean ride on the hidden layer's normalise-backward pass, which then works from the
+        # pre-activation rows (kept by the forward's normalise pass).  SAGE_NO_FUSED_POOL_LOGIT=1: the
+        # separate kernels.
+        self.fused_pool = (self.pool and not unsup and not self.multilabel and len(model.layers) >= 2
+                           and ops.logit_layer_supported(last_w.size(1), last_w.size(0))
+                           and not os.environ.get('SAGE_NO_FUSED_POOL_LOGIT'))
         self.writers = None         # per sample slot, filled in below once the buffers exist
         self.features, self.labels = features, labels
         self.B = int(batch_size)
@@ -254,7 +264,7 @@ class SageTrainEngine:
                      for _ in range(self.nslots)]
         self.ctrl = torch.zeros(ops.CTRL_WORDS, dtype=torch.int64, device=dev)
         self._stamp = 0
-        if self.logit_fwdbwd and not os.environ.get('SAGE_NO_SOLO_ROWS'):
+        if (self.logit_fwdbwd or self.fused_pool) and not os.environ.get('SAGE_NO_SOLO_ROWS'):
             # writers per row of the hidden layer's gradient (rows = the targets of layer L-2), per slot
             self.writers = [torch.zeros(self.hop_cap[1], dtype=torch.int32, device=dev) for _ in range(self.nslots)]
         # device-side row counts per slot: n_dev[slot][h] = #nodes after hop h
@@ -423,7 +433,8 @@ class SageTrainEngine:
         self.rev_up = None
         if self.rev is not None and self.reduce == 'mean' and self.L >= 2 and not os.environ.get('SAGE_NO_POOL_PULL_UP'):
             self.rev_up = {i: [ops.ReverseEdges(self.act[i]['s_cap'], self.act[i]['t_cap'] * max(fan), dev)
-                               for _ in range(self.nslots)] for i in range(1, self.L)}
+                               for _ in range(self.nslots)]
+                           for i in range(1, self.L) if not (self.fused_pool and i == self.L - 1)}
         if self.unsup:
             self.pos_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
             self.neg_id = torch.zeros(self.hop_cap[-1], dtype=torch.int64, device=dev)
@@ -691,7 +702,9 @@ class SageTrainEngine:
         # layer 0 stores every row itself)
         ops.pool_linear_fwd(x, layer.pool.weight, layer.pool.bias, m=a['s_cap'],
                             m_dev=self.n_dev[slot][a['src_hop']], rows=node_map, out=a['P'],
-                            dpre=None if ((i == 0 and self.rev is not None) or (i > 0 and self.rev_up is not None)) else a['dpre'])
+                            dpre=None if ((i == 0 and self.rev is not None) or
+                                          (i > 0 and self.rev_up is not None and i in self.rev_up))
+                            else a['dpre'])
 
     @staticmethod
     def _lstm_blocks(fdim):
@@ -769,8 +782,8 @@ class SageTrainEngine:
             self.make_pos_neg(slot, self.slot_counter[slot])
 
         def both():
-            self._forward(slot, skip_gather0, fused=self.fused_logit)
-            self._backward(slot, fused=self.fused_logit)
+            self._forward(slot, skip_gather0, fused=self.fused_logit or self.fused_pool)
+            self._backward(slot, fused=self.fused_logit or self.fused_pool)
         self._taped('fb%d' % skip_gather0, slot, both)
 
     def forward(self, slot=0, skip_gather0=False):
@@ -790,7 +803,7 @@ class SageTrainEngine:
     def _agg0(self, slot, v):
         return self.agg0[slot] if v == 0 else self.acts[v][0]['agg']
 
-    def _forward_layers(self, slot, v, skip_gather0, upto=None, raw_last=False):
+    def _forward_layers(self, slot, v, skip_gather0, upto=None, raw_last=False, keep_z_last=False):
         """Layers of variant v up to the un-normalised logits z (or only the first `upto`;
         raw_last: the last of those is left as its pre-activation rows z — the fused class-logit
         kernel normalises what it reads)."""
@@ -827,12 +840,22 @@ class SageTrainEngine:
                                   m_dev=t_dev, rows2=node_map if self.root else None, out=a['z'],
                                   accumulate=(i < L - 1 or not self.unsup))
             if i < L - 1 and not (raw_last and i == upto - 1):
+                # (keep_z_last: the backward of that layer works from z, sage_l2norm_relu_bwd_z_dw, and clears it)
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'],
-                                    clear_z=True)
+                                    clear_z=not (keep_z_last and i == upto - 1))
             x, node_map = a.get('h'), None
 
     def _forward(self, slot, skip_gather0, fused=False):
         buf, lib, B = self.bufs[slot], ops, self.B
+        if fused and self.fused_pool:
+            self._forward_layers(slot, 0, skip_gather0, upto=self.L - 1, keep_z_last=True)
+            last, layer, prev = self.act[-1], self.model.layers[-1], self.act[-2]
+            self._pool_forward(slot, self.L - 1, prev['h'], None)       # P = relu(pool(h)); d pre handed back zeroed
+            lib.logit_layer_pool_fwd_bwd(prev['h'], last['P'], buf.seg_ptr, buf.src, B, self.reduce, layer.lin_l.weight,
+                                         layer.lin_r.weight, self.labels, buf.node, last['agg'], last['y'], last['inv'],
+                                         last['dz'], self.row_loss, prev['dh'], last['dpre'],
+                                         writers=self.writers[slot] if self.writers is not None else None)
+            return
         if fused:
             # (training step only: the loss mean then comes out of the backward launch)
             self._forward_layers(slot, 0, skip_gather0, upto=self.L - 1, raw_last=self.prenorm)
@@ -903,7 +926,7 @@ class SageTrainEngine:
             a, layer = act[i], self.model.layers[i]
             t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
             if i < L - 1:   # g = gradient w.r.t. relu(normalize(z)), left in dh by layer i+1
-                if fused and self.logit_fwdbwd and i == L - 2:
+                if fused and (self.logit_fwdbwd or self.fused_pool) and i == L - 2:
                     nxt, lay2 = act[i + 1], self.model.layers[i + 1]
                     lib.l2norm_relu_bwd_z_dw(a['dh'], a['z'], True, t_cap, t_dev, a['dz'], True,
                                              nxt['dz'], self.B, self.n_dev[slot][nxt['hop']], nxt['agg'],
@@ -920,6 +943,10 @@ class SageTrainEngine:
             agg_i = self._agg0(slot, v) if i == 0 else a['agg']
             if fused and i == L - 1 and self.logit_fwdbwd:
                 continue      # input gradient: done by the forward launch; weight gradients: ride on layer i-1's pass
+            if fused and i == L - 1 and self.fused_pool:
+                # the same, and what is left of the layer is the pool Linear's own backward
+                self._pool_backward(slot, i, x_in, rows, edge_pass=False)
+                continue
             if fused and i == L - 1 and self.fused_logit_dw:
                 # the class-logit layer's backward and its two (skinny) weight gradients in one
                 # launch: the gradients' workgroups run on the CUs the 128 seed workgroups leave idle
@@ -985,13 +1012,15 @@ class SageTrainEngine:
         else:
             ops.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
 
-    def _pool_backward(self, slot, i, x_in, rows):
+    def _pool_backward(self, slot, i, x_in, rows, edge_pass=True):
         """Layer i's aggregate path with a pooling aggregator: d agg -> (through the reduce) d P ->
         (relu) d pool(x) -> pool weight / bias gradients and, above layer 0, the input gradient."""
         a, layer, buf, lib = self.act[i], self.model.layers[i], self.bufs[slot], ops
         t_cap, t_dev = a['t_cap'], self.n_dev[slot][a['hop']]
         s_cap, s_dev = a['s_cap'], self.n_dev[slot][a['src_hop']]
-        if i > 0:      # root term into the previous layer's dh (overwrites its first t rows), d agg beside it
+        if not edge_pass:
+            pass       # (the fused last layer: d pre is there already, the root term too)
+        elif i > 0:      # root term into the previous layer's dh (overwrites its first t rows), d agg beside it
             lib.linear_dinput2(a['dz'], layer.lin_r.weight, self.act[i - 1]['dh'], layer.lin_l.weight, a['dagg'],
                                m=t_cap, m_dev=t_dev)
         else:
@@ -1000,12 +1029,14 @@ class SageTrainEngine:
         # 0; the B seed rows of the layers above are routed with atomics throughout
         # (max_pool 1.199 against 1.212 ms per step, mean_pool unchanged; scratch/pool_indeg_ab.sh)
         indeg = a['indeg'] if (t_cap >= 4096 or os.environ.get('SAGE_POOL_INDEG_ALL')) else None
-        if i == 0 and self.rev is not None:
+        if not edge_pass:
+            pass
+        elif i == 0 and self.rev is not None:
             if self.reduce == 'max':
                 lib.pool_max_bwd_pull(a['dagg'], a['arg8'], self.rev[slot], a['dpre'], num_sources_dev=s_dev)
             else:
                 lib.pool_mean_bwd_pull(a['dagg'], a['P'], buf.seg_ptr, self.rev[slot], a['dpre'], num_sources_dev=s_dev)
-        elif i > 0 and self.rev_up is not None:
+        elif i > 0 and self.rev_up is not None and i in self.rev_up:
             lib.pool_mean_bwd_pull(a['dagg'], a['P'], buf.seg_ptr, self.rev_up[i][slot], a['dpre'], num_sources_dev=s_dev)
         elif self.reduce == 'max':
             agg_i = self.agg0[slot] if i == 0 else a['agg']

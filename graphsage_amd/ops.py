@@ -1022,6 +1022,41 @@ def logit_layer_fwd(h_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_row
                                             _stream()), "sage_logit_layer_fwd_bwd")
 
 
+def logit_layer_pool_fwd_bwd(h_rows, p_rows, seg_ptr, src, m, reduce, w_l, w_r, labels, label_rows, agg, y, inv_norm, dz,
+                             row_loss, dh, dpre, grad_scale=1.0, writers=None):
+    """logit_layer_fwd(dh=...) for the last layer of a pooling aggregator (reference layers/sage.py:201-210):
+    neighbour rows from p_rows = relu(pool(h)) (indexed like h_rows), root row h_rows[t]; reduce 'mean' / 'max'.
+    dh[:m] = dz . W_r (stored), dpre[src] += the neighbours' share through the relu (dpre holds zeros on entry)."""
+    lib = _lib.load()
+    hp, ld_h = _mat(h_rows, "h_rows")
+    pp, ld_p = _mat(p_rows, "p_rows")
+    wlp, ld_wl = _mat(w_l, "w_l")
+    wrp, ld_wr = _mat(w_r, "w_r")
+    n, h = w_l.shape
+    m = int(m)
+    ap, ld_agg = _mat(agg, "agg")
+    dp, ld_dz = _mat(dz, "dz")
+    yp, ld_y = (None, 0) if y is None else _mat(y, "y")
+    gp, ld_dh = _mat(dh, "dh")
+    zp, ld_dpre = _mat(dpre, "dpre")
+    if h_rows.size(1) != h or p_rows.size(1) != h or tuple(w_r.shape) != (n, h) or m <= 0 or h_rows.size(0) < m \
+            or agg.size(0) < m or agg.size(1) != h or dz.size(0) < m or dz.size(1) != n or row_loss.numel() < m \
+            or seg_ptr.numel() < m + 1 or (y is not None and (y.size(0) < m or y.size(1) != n)) \
+            or (inv_norm is not None and inv_norm.numel() < m) or dh.size(1) != h or dh.size(0) < m \
+            or dpre.size(1) != h or dpre.size(0) < p_rows.size(0) \
+            or (label_rows is not None and label_rows.numel() < m) or (label_rows is None and labels.numel() < m):
+        raise RuntimeError("logit_layer_pool_fwd_bwd: bad buffers")
+    if writers is not None and (writers.dtype != torch.int32 or writers.numel() < p_rows.size(0) or not writers.is_contiguous()):
+        raise RuntimeError("logit_layer_pool_fwd_bwd: writers must be a contiguous int32 tensor with one entry per row of p_rows")
+    rc = lib.sage_logit_layer_pool_fwd_bwd(hp, ld_h, pp, ld_p, _vec(seg_ptr, torch.int64, "seg_ptr"), _vec(src, torch.int64, "src"),
+                                           m, h, REDUCE[reduce], wlp, ld_wl, wrp, ld_wr, n, _vec(labels, torch.int64, "labels"),
+                                           _vec(label_rows, torch.int64, "label_rows", allow_none=True), float(grad_scale),
+                                           ap, ld_agg, yp, ld_y, _vec(inv_norm, torch.float32, "inv_norm", allow_none=True),
+                                           dp, ld_dz, _vec(row_loss, torch.float32, "row_loss"), gp, ld_dh, zp, ld_dpre,
+                                           _p(writers, torch.int32, "writers", allow_none=True), _stream())
+    _lib.check(rc, "sage_logit_layer_pool_fwd_bwd")
+
+
 def count_row_writers(seg_ptr, src, m, writers, max_edges=None):
     """writers[r] = number of edges of the first m segments whose source is row r, + 1 for r < m
     (sage_count_row_writers; what logit_layer_fwd(dh=..., writers=...) wants)."""

@@ -636,6 +636,24 @@ int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, const sage_i64*
                                                    rows of dh with ONE writer are stored instead of added
                                                    (dh must then hold zeros on entry) */,
                              void* stream);
+/* The same one-launch forward + backward for the last layer of a POOLING aggregator (reference
+ * layers/sage.py:201-210 with :124-132 behind it): the neighbour rows are read from p_rows =
+ * relu(pool(h)) (one row per source node, indexed like h_rows), the root row from h_rows[t]; both
+ * as they are (no normalisation on the way in).  reduce = mean or max.  Backward: dh[t] (rows <
+ * m) = dz . W_r, stored; dpre[src] += the neighbours' share of dz . W_l THROUGH the relu — mean:
+ * (dz . W_l) / deg where p_rows[src] > 0, max: each column to the row that supplied the maximum,
+ * where that maximum is positive.  dpre holds zeros on entry.  writers as in
+ * sage_logit_layer_fwd_bwd (sage_count_row_writers over the seeds' segments): a row of dpre whose
+ * only in-edge is this seed's is stored instead of added.  Weight gradients and the loss mean:
+ * from dz / agg / row_loss as for sage_logit_layer_fwd (sage_linear_dweight2_loss). */
+int sage_logit_layer_pool_fwd_bwd(const float* h_rows, sage_i64 ld_h, const float* p_rows, sage_i64 ld_p,
+                                  const sage_i64* seg_ptr, const sage_i64* src, sage_i64 m, int h, int reduce,
+                                  const float* w_l, sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n,
+                                  const sage_i64* labels, const sage_i64* label_rows, float grad_scale,
+                                  float* agg, sage_i64 ld_agg, float* y, sage_i64 ld_y, float* inv_norm,
+                                  float* dz, sage_i64 ld_dz, float* row_loss, float* dh, sage_i64 ld_dh,
+                                  float* dpre, sage_i64 ld_dpre, const int* writers, void* stream);
+
 /* writers[r] (int32, r < rows) = the number of waves of sage_logit_layer_fwd_bwd that add into row r
  * of dh: the edges e in [seg_ptr[0], seg_ptr[m]) with src[e] == r, plus one for r < m (a seed's
  * own row).  max_edges bounds seg_ptr[m] - seg_ptr[0] (the launch is sized by it).  Two short

@@ -969,6 +969,70 @@ def test_logit_layer_on_preactivation_rows(dev, reduce, h, n):
                                  gbuf[n:, :h])
 
 
+@pytest.mark.parametrize("reduce", ["mean", "max"])
+@pytest.mark.parametrize("h,n,use_writers", [(256, 41, True), (256, 41, False), (64, 7, True), (512, 40, True), (36, 5, False)])
+def test_logit_layer_pool_fwd_bwd_matches_torch(dev, h, n, use_writers, reduce):
+    """sage_logit_layer_pool_fwd_bwd — the last layer of max_pool / mean_pool in one launch (neighbour rows
+    from P = relu(pool(h)), root row from h; reference layers/sage.py:201-210, :124-132) — loss, d z, kept
+    aggregate, the root rows' gradient and the gradient of pool(h) THROUGH the relu against torch autograd
+    in float64 on ragged segments (empty, longer than a wave), rows with one in-edge stored / added."""
+    from graphsage_amd import ops
+    g = torch.Generator(device=dev).manual_seed(41 + h)
+    m, n_src = 77, 400
+    ldh = (h + 15) // 16 * 16
+    hbuf = torch.randn(n_src, ldh, generator=g, device=dev)[:, :h]
+    pre = torch.randn(n_src, ldh, generator=g, device=dev)[:, :h]
+    P = torch.zeros(n_src, ldh, device=dev)[:, :h]
+    P.copy_(pre.relu())
+    deg = torch.randint(0, 30, (m,), generator=g, device=dev)
+    deg[3], deg[5] = 0, 70
+    seg_ptr = torch.zeros(m + 1, dtype=torch.int64, device=dev)
+    seg_ptr[1:] = deg.cumsum(0)
+    E = int(seg_ptr[-1])
+    src = torch.randint(0, n_src, (E,), generator=g, device=dev)
+    wbuf = torch.randn(2 * n, ldh, generator=g, device=dev) * 0.2
+    w_l, w_r = wbuf[:n, :h], wbuf[n:, :h]
+    labels = torch.randint(0, n, (m,), generator=g, device=dev)
+    agg = torch.zeros(m, ldh, device=dev)[:, :h]
+    y, dz = torch.zeros(m, 64, device=dev)[:, :n], torch.zeros(m, 64, device=dev)[:, :n]
+    inv, rl = torch.zeros(m, device=dev), torch.zeros(m, device=dev)
+    dh = torch.full((n_src, ldh), 9.0, device=dev)[:, :h]
+    dh[:m] = 0.0
+    dpre = torch.zeros(n_src, ldh, device=dev)[:, :h]
+    writers = None
+    if use_writers:
+        writers = torch.zeros(n_src, dtype=torch.int32, device=dev)
+        ops.count_row_writers(seg_ptr, src, m, writers)
+    ops.logit_layer_pool_fwd_bwd(hbuf, P, seg_ptr, src, m, reduce, w_l, w_r, labels, None, agg, y, inv, dz, rl, dh, dpre,
+                                 writers=writers)
+    # float64 autograd of the reference's formulation
+    pre64 = pre.double().requires_grad_(True)
+    h64 = hbuf.double().requires_grad_(True)
+    P64 = pre64.relu()
+    tgt = torch.repeat_interleave(torch.arange(m, device=dev), deg)
+    if reduce == "mean":
+        a64 = torch.zeros(m, h, dtype=torch.float64, device=dev).index_add(0, tgt, P64[src]) / deg.clamp(min=1).double()[:, None]
+    else:
+        a64 = torch.zeros(m, h, dtype=torch.float64, device=dev).scatter_reduce(
+            0, tgt.unsqueeze(1).expand(-1, h), P64[src], "amax", include_self=False)
+    z64 = a64 @ w_l.double().t() + h64[:m] @ w_r.double().t()
+    z64.retain_grad()
+    y64 = torch.nn.functional.normalize(z64, dim=1)
+    rows64 = torch.nn.functional.cross_entropy(y64, labels, reduction="none")
+    rows64.mean().backward()
+    torch.testing.assert_close(agg.double(), a64.detach(), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(y.double(), y64.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rl.double(), rows64.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dz.double(), z64.grad, rtol=1e-4, atol=1e-7)
+    torch.testing.assert_close(dh[:m].double(), h64.grad[:m], rtol=1e-4, atol=1e-7)
+    assert float(dh[m:].min()) == 9.0 and float(dh[m:].max()) == 9.0          # only the seeds' rows of dh are written
+    # (max: ties between equal positive values of different rows do not occur with random rows; autograd
+    # splits the gradient among tied maxima, the kernel routes to the first — column sums agree either way)
+    torch.testing.assert_close(dpre.double(), pre64.grad, rtol=1e-4, atol=1e-7)
+    with pytest.raises(RuntimeError, match="mean or max"):
+        ops.logit_layer_pool_fwd_bwd(hbuf, P, seg_ptr, src, m, "sum", w_l, w_r, labels, None, agg, y, inv, dz, rl, dh, dpre)
+
+
 def test_logit_layer_rejects_weights_beyond_lds(dev):
     from graphsage_amd import ops
     assert not ops.logit_layer_supported(512, 64) and ops.logit_layer_supported(512, 40)
