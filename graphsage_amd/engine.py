@@ -27,7 +27,11 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
   * the pooling aggregators keep P = relu(pool(x)) per SOURCE row of a layer in a static buffer
     and route d agg back through the reduce and the ReLU in one edge pass
     (sage_pool_linear_fwd / sage_pool_max_bwd / sage_pool_mean_bwd); their large weight
-    gradients run on a forked stream beside that pass;
+    gradients run on a forked stream beside that pass; at Reddit size layer 0's edge pass is
+    pulled by the source rows from per-source edge lists built behind the sampler
+    (sage_pool_reverse_edges / sage_pool_*_bwd_pull), and their last layer is one launch like the
+    class-logit layer above (sage_logit_layer_pool_fwd_bwd); evaluate() computes relu(pool(x)) once
+    over all nodes when the batches together exceed the graph;
   * the lstm aggregator (reference layers/sage.py:67-69, :147-193 as read in layers/lstm.py)
     materialises the cell's flattened input x_flat [targets, n_in * F] once per layer and step
     (sage_lstm_gather_flat: 0.8 GB at the Reddit shape, static, in 288 GB of HBM), so that the
