@@ -13,8 +13,9 @@
 //     (what autograd derives for the two Linears and the scatter; rows that only one seed writes
 //     are stored instead of added; max sends each column to the row that supplied it)
 //   forward only (sage_logit_layer_infer): the arg-max class of every seed row.
-//   The training step's common shape (H = 256, mean / sum / gcn, pre-activation rows) runs forward +
-//   backward with FOUR waves per seed (logit_fb4_kernel), everything else with one (logit_fwd_kernel).
+//   The training step's common shape (H = 256; mean / sum / max / gcn on pre-activation rows, the
+//   pooling aggregators' last layer) runs forward + backward with FOUR waves per seed
+//   (logit_fb4_kernel), everything else with one (logit_fwd_kernel).
 // The layer's weight gradients and the loss mean need every seed's dz: they ride as extra
 // workgroups in front of another launch's grid (skinny_dw.h; rowops.hip's normalise-backward pass
 // in the engine's step, or logit_bwd_dw_kernel below).
@@ -634,6 +635,7 @@ logit_fwd_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
 constexpr int kFb4Block = 512;
 constexpr int kFb4H = 256;
 constexpr int kFb4Extra = 2 * (2 * 4 * kFb4H) + 2 * 64;      // floats of LDS behind the weights
+constexpr int kFb4ExtraMax = 2 * 4 * kFb4H + 2 * kFb4H;      // ... and behind those with MAX (edges: partial, final)
 
 // GCN (layers/sage.py:114-117): the neighbour rows and ONE self-loop averaged for targets that have
 // neighbours, no root weight (w_r is not read for the products), the target's own row takes the
@@ -641,7 +643,11 @@ constexpr int kFb4Extra = 2 * (2 * 4 * kFb4H) + 2 * 64;      // floats of LDS be
 // POOL (the pooling aggregators' last layer, mean; as `prows` of logit_fwd_kernel): rows as they are
 // (no normalisation on the way in), the neighbour rows from prows = relu(pool(h)), their share of the
 // backward through the relu into dnb, the root's into dh (stored: its one writer).
-template <bool GCN, bool POOL = false>
+// MAX: the neighbour reduce is the element-wise maximum (first edge on ties, 0 for an empty segment);
+// every wave keeps (maximum, edge) of its rows, the four pairs meet in LDS (equal maxima: the lower
+// edge), and the backward sends each column's gradient to the one row that supplied it (POOL: where
+// that maximum is positive) — wave `sub` takes columns lane + 64 sub.
+template <bool GCN, bool POOL = false, bool MAX = false>
 __global__ void __launch_bounds__(kFb4Block, 2)      // (two waves per SIMD: the register file is the wave's up to 256 VGPRs)
 logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* __restrict__ seg_ptr,
                  const int64_t* __restrict__ src, int64_t m, int mean,
@@ -661,6 +667,8 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   float* const part_a = wlds + static_cast<int64_t>(n) * 2 * H;      // [2 seeds][4 waves][H]
   float* const part_r = part_a + 2 * 4 * H;
   float* const zb = part_r + 2 * 4 * H;                               // [2 seeds][64]
+  int* const part_g = reinterpret_cast<int*>(zb + 2 * 64);            // MAX: [2 seeds][4 waves][H] edges of the partial maxima
+  int* const argc = part_g + 2 * 4 * H;                               // MAX: [2 seeds][H] the edge each column's gradient goes to
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x) / kWave);
   const int sd = wave >> 2, sub = wave & 3;
@@ -713,7 +721,8 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       if (r < chunk) x[i] = reinterpret_cast<const float4*>(nbase + readlane64(my, r) * ld_n)[lane];
     }
   };
-  auto add_rows = [&](float4 (&x)[8], int r0, int chunk) __attribute__((always_inline)) {
+  int arg[4] = {-1, -1, -1, -1};      // MAX: the edge (relative to s0) behind each of this wave's maxima
+  auto add_rows = [&](float4 (&x)[8], int r0, int chunk, int base) __attribute__((always_inline)) {
     float ss[8];
     if (!POOL) {
 #pragma unroll
@@ -723,10 +732,24 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
     for (int i = 0; i < 8; ++i) {
       if (r0 + 4 * i < chunk) {
         if (!POOL) activate(x[i], ss[i]);
-        acc.x += x[i].x;
-        acc.y += x[i].y;
-        acc.z += x[i].z;
-        acc.w += x[i].w;
+        if (MAX) {
+          const int e = base + r0 + 4 * i;
+          auto upd = [&](float& a, int& g, float val) {
+            if (g < 0 || val > a) {
+              a = val;
+              g = e;
+            }
+          };
+          upd(acc.x, arg[0], x[i].x);
+          upd(acc.y, arg[1], x[i].y);
+          upd(acc.z, arg[2], x[i].z);
+          upd(acc.w, arg[3], x[i].w);
+        } else {
+          acc.x += x[i].x;
+          acc.y += x[i].y;
+          acc.z += x[i].z;
+          acc.w += x[i].w;
+        }
       }
     }
   };
@@ -743,10 +766,10 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       *reinterpret_cast<float4*>(row + H) = vr[b];
     }
   }
-  add_rows(x, sub, chunk0);
+  add_rows(x, sub, chunk0, 0);
   for (int r0 = sub + 32; r0 < chunk0; r0 += 32) {
     load_rows(x, my0, r0, chunk0);
-    add_rows(x, r0, chunk0);
+    add_rows(x, r0, chunk0, 0);
   }
   if (live) {
     for (int64_t base = kWave; base < len; base += kWave) {
@@ -755,7 +778,7 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       if (lane < chunk) my = src[s0 + base + lane];
       for (int r0 = sub; r0 < chunk; r0 += 32) {
         load_rows(x, my, r0, chunk);
-        add_rows(x, r0, chunk);
+        add_rows(x, r0, chunk, static_cast<int>(base));
       }
     }
   }
@@ -769,18 +792,47 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
   }
   LOGIT_STAMP(0, 2);
   *reinterpret_cast<float4*>(part_a + (sd * 4 + sub) * H + 4 * lane) = acc;
+  if (MAX) *reinterpret_cast<int4*>(part_g + (sd * 4 + sub) * H + 4 * lane) = make_int4(arg[0], arg[1], arg[2], arg[3]);
   __syncthreads();
 
   LOGIT_STAMP(0, 3);
   // the seed's aggregate (every wave of the seed adds the four parts up for itself)
   float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MAX) {
+    int4 g4 = make_int4(-1, -1, -1, -1);
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const float4 q = *reinterpret_cast<const float4*>(part_a + (sd * 4 + s) * H + 4 * lane);
-    a4.x += q.x;
-    a4.y += q.y;
-    a4.z += q.z;
-    a4.w += q.w;
+    for (int s = 0; s < 4; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(part_a + (sd * 4 + s) * H + 4 * lane);
+      const int4 g = *reinterpret_cast<const int4*>(part_g + (sd * 4 + s) * H + 4 * lane);
+      auto pick = [](float& bv, int& bg, float v, int e) {
+        if (e >= 0 && (bg < 0 || v > bv || (v == bv && e < bg))) {
+          bv = v;
+          bg = e;
+        }
+      };
+      pick(a4.x, g4.x, q.x, g.x);
+      pick(a4.y, g4.y, q.y, g.y);
+      pick(a4.z, g4.z, q.z, g.z);
+      pick(a4.w, g4.w, q.w, g.w);
+    }
+    if (sub == 0) {      // where each column's gradient goes (POOL: only through a positive maximum)
+      if (POOL) {
+        if (!(a4.x > 0.f)) g4.x = -1;
+        if (!(a4.y > 0.f)) g4.y = -1;
+        if (!(a4.z > 0.f)) g4.z = -1;
+        if (!(a4.w > 0.f)) g4.w = -1;
+      }
+      *reinterpret_cast<int4*>(argc + sd * H + 4 * lane) = g4;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 q = *reinterpret_cast<const float4*>(part_a + (sd * 4 + s) * H + 4 * lane);
+      a4.x += q.x;
+      a4.y += q.y;
+      a4.z += q.z;
+      a4.w += q.w;
+    }
   }
   if (GCN) {
     if (len > 0) {
@@ -790,7 +842,7 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
       a4.z = (a4.z + root.z) / cnt;
       a4.w = (a4.w + root.w) / cnt;
     }
-  } else if (mean) {
+  } else if (!MAX && mean) {
     const float cnt = len > 0 ? static_cast<float>(len) : 1.f;
     a4.x /= cnt;
     a4.y /= cnt;
@@ -921,6 +973,13 @@ logit_fb4_kernel(const float* __restrict__ hrows, int64_t ld_h, const int64_t* _
     }
   }
   if (len <= 0) return;
+  if (MAX) {      // one add per column: this wave takes columns lane + 64 sub
+    const int g = argc[sd * H + lane + kWave * sub];
+    const float dv = sub == 0 ? da[0] : (sub == 1 ? da[1] : (sub == 2 ? da[2] : da[3]));      // (wave-uniform selects)
+    if (g >= 0) atomicAdd(nsink + src[s0 + g] * ld_ns + lane + kWave * sub, dv);
+    LOGIT_STAMP(0, 7);
+    return;
+  }
   if (!GCN && mean) {
     const float cnt = static_cast<float>(len);
 #pragma unroll
@@ -1172,11 +1231,20 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
   // the training step's common case: four waves per seed (SAGE_LOGIT_ONE_WAVE=1: the general kernel)
   static const bool one_wave = getenv("SAGE_LOGIT_ONE_WAVE") != nullptr;
   const size_t lds4 = lds + kFb4Extra * sizeof(float);
+  const size_t lds4m = lds4 + kFb4ExtraMax * sizeof(float);
   if (!one_wave && prows == nullptr && dh != nullptr && pre && h == kFb4H &&
-      (reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_GCN) && pred == nullptr &&
-      dz != nullptr && agg != nullptr && labels != nullptr && row_loss != nullptr && h_root != nullptr && lds4 <= 160 * 1024) {
+      (reduce == SAGE_REDUCE_MEAN || reduce == SAGE_REDUCE_SUM || reduce == SAGE_REDUCE_GCN ||
+       (reduce == SAGE_REDUCE_MAX && lds4m <= 160 * 1024)) &&
+      pred == nullptr && dz != nullptr && agg != nullptr && labels != nullptr && row_loss != nullptr && h_root != nullptr &&
+      lds4 <= 160 * 1024) {
     const unsigned grid4 = static_cast<unsigned>(cdiv(m, 2));
-    if (reduce == SAGE_REDUCE_GCN) {
+    if (reduce == SAGE_REDUCE_MAX) {
+      const int rc4 = allow_lds(logit_fb4_kernel<false, false, true>, lds4m, who);
+      if (rc4 != SAGE_OK) return rc4;
+      logit_fb4_kernel<false, false, true><<<grid4, kFb4Block, lds4m, stream>>>(
+          h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
+          inv_norm, dz, ld_dz, row_loss, h_root, ld_h_root, dh, ld_dh, writers, nullptr, 0, nullptr, 0);
+    } else if (reduce == SAGE_REDUCE_GCN) {
       const int rc4 = allow_lds(logit_fb4_kernel<true>, lds4, who);
       if (rc4 != SAGE_OK) return rc4;
       logit_fb4_kernel<true><<<grid4, kFb4Block, lds4, stream>>>(
@@ -1193,13 +1261,23 @@ int launch_logit_fwd(const char* who, bool pre, const float* h_rows, sage_i64 ld
     return SAGE_OK;
   }
   // ... and the pooling aggregators' last layer with the mean (sage_logit_layer_pool_fwd_bwd)
-  if (!one_wave && prows != nullptr && dnb != nullptr && dh != nullptr && !pre && h == kFb4H && reduce == SAGE_REDUCE_MEAN &&
-      pred == nullptr && dz != nullptr && agg != nullptr && labels != nullptr && row_loss != nullptr && lds4 <= 160 * 1024) {
-    const int rc4 = allow_lds(logit_fb4_kernel<false, true>, lds4, who);
-    if (rc4 != SAGE_OK) return rc4;
-    logit_fb4_kernel<false, true><<<static_cast<unsigned>(cdiv(m, 2)), kFb4Block, lds4, stream>>>(
-        h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
-        inv_norm, dz, ld_dz, row_loss, nullptr, 0, dh, ld_dh, writers, prows, ld_p, dnb, ld_dnb);
+  if (!one_wave && prows != nullptr && dnb != nullptr && dh != nullptr && !pre && h == kFb4H &&
+      (reduce == SAGE_REDUCE_MEAN || (reduce == SAGE_REDUCE_MAX && lds4m <= 160 * 1024)) && pred == nullptr && dz != nullptr &&
+      agg != nullptr && labels != nullptr && row_loss != nullptr && lds4 <= 160 * 1024) {
+    const unsigned grid4 = static_cast<unsigned>(cdiv(m, 2));
+    if (reduce == SAGE_REDUCE_MAX) {
+      const int rc4 = allow_lds(logit_fb4_kernel<false, true, true>, lds4m, who);
+      if (rc4 != SAGE_OK) return rc4;
+      logit_fb4_kernel<false, true, true><<<grid4, kFb4Block, lds4m, stream>>>(
+          h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
+          inv_norm, dz, ld_dz, row_loss, nullptr, 0, dh, ld_dh, writers, prows, ld_p, dnb, ld_dnb);
+    } else {
+      const int rc4 = allow_lds(logit_fb4_kernel<false, true, false>, lds4, who);
+      if (rc4 != SAGE_OK) return rc4;
+      logit_fb4_kernel<false, true, false><<<grid4, kFb4Block, lds4, stream>>>(
+          h_rows, ld_h, seg_ptr, src, m, mean, w_l, ld_wl, w_r, ld_wr, n, labels, label_rows, grad_scale, agg, ld_agg, y, ld_y,
+          inv_norm, dz, ld_dz, row_loss, nullptr, 0, dh, ld_dh, writers, prows, ld_p, dnb, ld_dnb);
+    }
     SAGE_CHECK_LAUNCH("logit_fb4_kernel(pool)");
     return SAGE_OK;
   }
