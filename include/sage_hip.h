@@ -645,7 +645,9 @@ int sage_logit_layer_fwd_bwd(const float* h_rows, sage_i64 ld_h, const sage_i64*
  * where that maximum is positive.  dpre holds zeros on entry.  writers as in
  * sage_logit_layer_fwd_bwd (sage_count_row_writers over the seeds' segments): a row of dpre whose
  * only in-edge is this seed's is stored instead of added.  Weight gradients and the loss mean:
- * from dz / agg / row_loss as for sage_logit_layer_fwd (sage_linear_dweight2_loss). */
+ * from dz / agg / h_rows[:m] / row_loss, as behind sage_logit_layer_fwd_bwd (riding on
+ * sage_l2norm_relu_bwd_z_dw, or sage_linear_dweight2 + a mean of row_loss).  h = 256: four waves
+ * per seed; other widths: one. */
 int sage_logit_layer_pool_fwd_bwd(const float* h_rows, sage_i64 ld_h, const float* p_rows, sage_i64 ld_p,
                                   const sage_i64* seg_ptr, const sage_i64* src, sage_i64 m, int h, int reduce,
                                   const float* w_l, sage_i64 ld_wl, const float* w_r, sage_i64 ld_wr, int n,
