@@ -416,7 +416,8 @@ class SageTrainEngine:
         # atomics, no in-degree launches in the step, no zero-fill by the pool Linear) from the
         # batch's edges listed per source row, which the sampler's stream builds behind the sampler
         # (sage_pool_reverse_edges, per sample slot); max keeps its arg-max as one byte per (target,
-        # column).  The B seed rows of the layers above stay with the pushed pass.
+        # column).  (The layers above: mean_pool's take the same pass, rev_up below; the last layer
+        # is the fused launch, fused_pool.)
         # SAGE_NO_POOL_PULL=1: the pushed pass with its in-degree workspace for layer 0 too;
         # SAGE_POOL_PULL_ALL=1: pulled whatever the batch's size (below 4096 targets the lists cost
         # the sampler's stream more than the step gains; tests).
