@@ -62,12 +62,17 @@ def test_engine_matches_module_path(dev, aggregator, monkeypatch):
     assert int(engine.step_dev) == 4
 
 
-@pytest.mark.parametrize("aggregator,keep", [("mean", True), ("mean", False), ("sum", False), ("max", False), ("gcn", True)])
-def test_three_layer_engine_matches_module_path(dev, aggregator, keep):
+@pytest.mark.parametrize("aggregator,keep", [("mean", True), ("mean", False), ("sum", False), ("max", False), ("gcn", True),
+                                             ("max_pool", True), ("mean_pool", True)])
+def test_three_layer_engine_matches_module_path(dev, aggregator, keep, monkeypatch):
     """Three SAGE layers (reference models/graphsage.py:44-49 with num_layers = 3): the class-logit
     layer's one-launch forward + backward sits on layer 2, its riders on layer 1's pass, the stored
     weight-gradient slices on layer 0 (keep=False) — losses and, with keep_grads, every gradient
-    against the module path; weights after Adam either way."""
+    against the module path; weights after Adam either way.  The pooling aggregators: their one-launch
+    last layer on layer 2, the riders on layer 1's pass, the pulled edge pass on layer 0 and (mean_pool)
+    layer 1."""
+    if aggregator.endswith("_pool"):
+        monkeypatch.setenv("SAGE_POOL_PULL_ALL", "1")
     from graphsage_amd.datasets import planted_partition
     from graphsage_amd.engine import SageTrainEngine
     from graphsage_amd.models import GraphSAGE
@@ -82,7 +87,11 @@ def test_three_layer_engine_matches_module_path(dev, aggregator, keep):
     graph = device_graph(data)
     engine = SageTrainEngine(model_b, NeighborSampler(data, fan, seed=5), graph.features(data), graph.labels(data), B,
                              lr=1e-2, keep_grads=keep)
-    assert engine.logit_fwdbwd and (engine.dw_parts is None) == keep          # (max as well: its arg-max stays in the wave)
+    if aggregator.endswith("_pool"):
+        assert engine.fused_pool and engine.rev is not None and (engine.rev_up is not None) == (aggregator == "mean_pool")
+        assert engine.rev_up is None or sorted(engine.rev_up) == [1]
+    else:
+        assert engine.logit_fwdbwd and (engine.dw_parts is None) == keep          # (max as well: its arg-max stays in the wave)
     opt = torch.optim.Adam(model_a.parameters(), lr=1e-2)
     for b, batch in enumerate(loader):
         opt.zero_grad()
