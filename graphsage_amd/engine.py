@@ -237,6 +237,8 @@ class SageTrainEngine:
             raise NotImplementedError("engine needs one non-negative fan-out per layer")
         dev = features.device
         self.dev = dev
+        self._dev_index = dev.index if dev.index is not None else torch.cuda.current_device()
+        self._cur_seen, self._cur_obj = None, None
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.world_size, self.pg = world_size, process_group
         # capacities: hop_cap[h] = max nodes after hop h
@@ -538,7 +540,7 @@ class SageTrainEngine:
         self._next_stamp(stream)
         if self.unsup:
             self.slot_counter[slot] = counter
-        handle = (stream or torch.cuda.current_stream()).cuda_stream
+        handle = stream.cuda_stream if stream is not None else self._cur_raw()
         key = ('sample', slot, handle)
         entry = self._tapes.get(key)
         if entry is None:
@@ -616,11 +618,25 @@ class SageTrainEngine:
         self._tapes.clear()        # (recorded again on the next eager call: one stream, no fork)
         self._main_touched = True
 
+    def _cur_raw(self):
+        """Raw handle of torch's current stream on the engine's device (torch.cuda.current_stream()
+        spends ~9 us of host time on device-index bookkeeping: four calls per step)."""
+        return torch._C._cuda_getCurrentRawStream(self._dev_index)
+
+    def _cur(self):
+        """torch.cuda.current_stream() of the engine's device, cached by its raw handle."""
+        raw = torch._C._cuda_getCurrentRawStream(self._dev_index)
+        if raw != self._cur_seen:
+            with torch.cuda.device(self._dev_index):
+                self._cur_obj = torch.cuda.current_stream()
+            self._cur_seen = raw
+        return self._cur_obj
+
     def _taped(self, what, slot, fn, stream=None):
         """Run fn() through the validating wrappers once per (what, slot, stream) and replay the
         recorded C-ABI calls afterwards: every pointer the engine passes is static.  `stream`
         (default: the current one) is where the calls go; a replay needs no stream switch."""
-        cur = torch.cuda.current_stream()
+        cur = self._cur()
         if not self.use_tapes:
             if stream is not None and stream != cur:
                 with torch.cuda.stream(stream):
@@ -1162,7 +1178,7 @@ class SageTrainEngine:
         if n - self.n_comp >= self.depth:
             raise RuntimeError("prefetch(): the pipeline is full")
         slot = n % self.nslots
-        main = torch.cuda.current_stream()
+        main = self._cur()
         need = n - self.nslots            # the batch that used this slot before
         if n < self.nslots or need > self.cons_rec_seq or self._main_touched:
             # first use of the slot, serial step()/evaluate() calls in between, or an irregular
@@ -1202,7 +1218,7 @@ class SageTrainEngine:
         i = self.n_comp
         p = i % self.nslots
         ov = self.overlap_gather
-        main = torch.cuda.current_stream()
+        main = self._cur()
         main_first = not self._side_first
         side_next = False
         signalled = None
@@ -1344,7 +1360,7 @@ class SageTrainEngine:
         if not self.use_tapes:
             run()
             return
-        key = (what, slot, torch.cuda.current_stream().cuda_stream)
+        key = (what, slot, self._cur_raw())
         entry = self._tapes.get(key)
         if entry is None:
             with _lib.recording() as tape:
