@@ -1382,6 +1382,19 @@ __global__ void zero_rows_kernel(float* out, int64_t ld, int64_t m, int n) {
   if (i < m * n) out[(i / n) * ld + (i % n)] = 0.f;
 }
 
+__global__ void zero_rows2_kernel(float* out1, int64_t ld1, float* out2, int64_t ld2, int64_t m,
+                                  const int64_t* m_dev, int n) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (m_dev != nullptr) {      // rows past the device-side count stay untouched, as in the whole-K launches
+    const int64_t v = *m_dev;
+    if (v < m) m = v;
+  }
+  if (i < m * n) {
+    float* const o = blockIdx.y ? out2 : out1;
+    o[(i / n) * (blockIdx.y ? ld2 : ld1) + (i % n)] = 0.f;
+  }
+}
+
 struct SkinnyArgs {
   Segment seg[2];
   int nseg;
@@ -1477,8 +1490,14 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
                "sage_linear_concat_fwd: NULL pointer argument");
   SAGE_REQUIRE(!(epilogue & SAGE_EPI_BIAS) || bias != nullptr, SAGE_EINVAL,
                "sage_linear_concat_fwd: SAGE_EPI_BIAS without bias");
-  SAGE_REQUIRE(!(epilogue & SAGE_EPI_ACCUM) || epilogue == SAGE_EPI_ACCUM, SAGE_EINVAL,
+  SAGE_REQUIRE(!(epilogue & SAGE_EPI_ACCUM) || (epilogue & ~SAGE_EPI_ZEROED) == SAGE_EPI_ACCUM, SAGE_EINVAL,
                "sage_linear_concat_fwd: SAGE_EPI_ACCUM excludes bias / relu");
+  SAGE_REQUIRE(!(epilogue & SAGE_EPI_ZEROED) || (epilogue & SAGE_EPI_ACCUM), SAGE_EINVAL,
+               "sage_linear_concat_fwd: SAGE_EPI_ZEROED qualifies SAGE_EPI_ACCUM");
+  // the addend is all zeros (the caller's promise): paths whose elements have one owner store
+  // instead of load-add-store, the others add into it without a fill pass as before
+  const bool zeroed = (epilogue & SAGE_EPI_ZEROED) != 0;
+  epilogue &= ~SAGE_EPI_ZEROED;
   GemmArgs g = {};
   g.seg[0].a = {a1, ld_a1, rows1, op_vec(a1, ld_a1, k1)};
   g.seg[0].b = {w1, ld_w1, nullptr, op_vec(w1, ld_w1, k1)};
@@ -1554,7 +1573,7 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
     if (x3_mode() && (plain || whole) && n > 64 && slots > 0 && vec4 && steps >= 6ll * slots) {
       if (whole) {
         g.whole = 1;
-        g.rmw_out = accum ? 1 : 0;
+        g.rmw_out = (accum && !zeroed) ? 1 : 0;
       } else if (!accum) {
         zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
         SAGE_CHECK_LAUNCH("zero_rows_kernel");
@@ -1587,7 +1606,7 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
     SAGE_CHECK_LAUNCH("gemm_kernel(fwd, stream-K)");
     return SAGE_OK;
   }
-  if (accum) g.rmw_out = 1;   // out += product: every element has one owner, plain load-add-store
+  if (accum && !zeroed) g.rmw_out = 1;   // out += product: every element has one owner, plain load-add-store
   return launch_gemm<true, true>(g, 1, stream, "gemm_kernel(fwd)");
 }
 
@@ -1665,6 +1684,41 @@ extern "C" int sage_linear_dinput2(const float* dout, sage_i64 ld_dout, const fl
     skinny_dinput_kernel<<<grid, kThreads, 0, stream>>>(s);
     SAGE_CHECK_LAUNCH("skinny_dinput_kernel(pair)");
     return SAGE_OK;
+  }
+  // Few output tiles (the 512 seed rows of a wide last layer: 8 x 2 tiles per product, whose 8
+  // dependent K-steps took 17 us per launch): both products in one grid (they share dout), the
+  // contraction split over blockIdx.z, partial sums added with fp32 atomics into zeroed outputs
+  // (SAGE_DINPUT2_SERIAL=1: the two whole-K launches, the A/B switch)
+  static const char* serial_env = getenv("SAGE_DINPUT2_SERIAL");
+  const int64_t tiles = cdiv(m, 64) * 2 * cdiv(k, 128);
+  if (!(serial_env && serial_env[0] == '1') && tiles <= 128 && n > 2 * BK) {
+    GemmArgs g = {};
+    g.seg[0].a = {dout, ld_dout, nullptr, op_vec(dout, ld_dout, n)};
+    g.seg[0].b = {w1, ld_w1, nullptr, op_vec(w1, ld_w1, k)};
+    g.seg[0].k = n;
+    g.seg[1].a = g.seg[0].a;
+    g.seg[1].b = {w2, ld_w2, nullptr, op_vec(w2, ld_w2, k)};
+    g.seg[1].k = n;
+    g.nseg = 2;
+    g.batched = 1;
+    g.m = m;
+    g.m_dev = m_dev;
+    g.n = k;
+    g.out = da1;
+    g.ld_out = ld_da1;
+    g.n2 = k;
+    g.out2 = da2;
+    g.ld_out2 = ld_da2;
+    g.ny0 = static_cast<int>(cdiv(k, 128));
+    g.atomic_out = 1;
+    int splits = static_cast<int>(cdiv(n, 2 * BK));      // two K-steps per slice, more beyond 8 slices
+    if (splits > 8) splits = 8;
+    g.k_chunk = static_cast<int>(cdiv(cdiv(n, splits), BK) * BK);
+    splits = static_cast<int>(cdiv(n, g.k_chunk));
+    const dim3 zgrid(static_cast<unsigned>(cdiv(m * k, kThreads)), 2);
+    zero_rows2_kernel<<<zgrid, kThreads, 0, stream>>>(da1, ld_da1, da2, ld_da2, m, m_dev, k);
+    SAGE_CHECK_LAUNCH("zero_rows2_kernel");
+    return launch_gemm<true, false>(g, splits, stream, "gemm_kernel(dinput pair, split-K)");
   }
   int rc = sage_linear_dinput(dout, ld_dout, w1, ld_w1, m, m_dev, n, k, da1, ld_da1, 0, stream_);
   if (rc != SAGE_OK) return rc;

@@ -222,6 +222,10 @@ class SageTrainEngine:
         # the loss mean ride on the hidden layer's normalise-backward pass, which then works from the
         # pre-activation rows (kept by the forward's normalise pass).  SAGE_NO_FUSED_POOL_LOGIT=1: the
         # separate kernels.
+        # every z the layers' contractions add into is handed back zeroed by its consumer: tell the
+        # contraction (SAGE_EPI_ZEROED), whose whole-tile shapes then store instead of load-add-store
+        # (SAGE_NO_ZEROED_HINT=1: the A/B switch)
+        self.zeroed_hint = not os.environ.get('SAGE_NO_ZEROED_HINT')
         self.fused_pool = (self.pool and not unsup and not self.multilabel and len(model.layers) >= 2
                            and ops.logit_layer_supported(last_w.size(1), last_w.size(0))
                            and not os.environ.get('SAGE_NO_FUSED_POOL_LOGIT'))
@@ -859,7 +863,8 @@ class SageTrainEngine:
             lib.linear_concat_fwd(agg, layer.lin_l.weight, x if self.root else None,
                                   layer.lin_r.weight if self.root else None, m=t_cap,
                                   m_dev=t_dev, rows2=node_map if self.root else None, out=a['z'],
-                                  accumulate=(i < L - 1 or not self.unsup))
+                                  accumulate='zeroed' if (i < L - 1 or not self.unsup) and self.zeroed_hint else
+                                  (i < L - 1 or not self.unsup))
             if i < L - 1 and not (raw_last and i == upto - 1):
                 # (keep_z_last: the backward of that layer works from z, sage_l2norm_relu_bwd_z_dw, and clears it)
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'],

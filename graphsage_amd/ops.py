@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 REDUCE = {"sum": 0, "add": 0, "mean": 1, "max": 2, "gcn": 3}
-EPI_NONE, EPI_BIAS, EPI_RELU, EPI_ACCUM = 0, 1, 2, 4
+EPI_NONE, EPI_BIAS, EPI_RELU, EPI_ACCUM, EPI_ZEROED = 0, 1, 2, 4, 8
 
 ST_NODES, ST_EDGES, ST_FRONT_BEGIN, ST_FRONT_END, ST_ERROR = 0, 1, 2, 3, 4
 ST_HOP_NODES, ST_HOP_EDGES, STATE_WORDS = 8, 24, 40
@@ -432,7 +432,9 @@ def linear_concat_fwd(a1, w1, a2=None, w2=None, bias=None, relu=False, m=None, m
                       rows1=None, rows2=None, out=None, accumulate=False):
     """out = a1[rows1] @ w1^T + a2[rows2] @ w2^T (+bias)(relu)
     (reference layers/sage.py:124-129; pool Linear :76,:202).  accumulate=True: out += product
-    (out must be given and hold the addend; excludes bias / relu)."""
+    (out must be given and hold the addend; excludes bias / relu); accumulate='zeroed': the same
+    with the caller's promise that the addend is all zeros (SAGE_EPI_ZEROED: shapes whose output
+    elements have one owner are then stored, not load-add-stored)."""
     lib = _lib.load()
     a1p, ld_a1 = _mat(a1, "a1")
     w1p, ld_w1 = _mat(w1, "w1")
@@ -464,7 +466,7 @@ def linear_concat_fwd(a1, w1, a2=None, w2=None, bias=None, relu=False, m=None, m
     if accumulate:
         if epi:
             raise RuntimeError("linear_concat_fwd: accumulate excludes bias / relu")
-        epi = EPI_ACCUM
+        epi = EPI_ACCUM | (EPI_ZEROED if accumulate == 'zeroed' else 0)
     if bias is not None and bias.numel() != n:
         raise RuntimeError("linear_concat_fwd: bias length != n")
     rc = lib.sage_linear_concat_fwd(a1p, ld_a1, _rows(rows1, m, "rows1"), k1, w1p, ld_w1,

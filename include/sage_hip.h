@@ -57,6 +57,11 @@ typedef int64_t sage_i64;
 #define SAGE_EPI_RELU 2 /* relu                 (layers/sage.py:202,206)               */
 #define SAGE_EPI_ACCUM 4 /* out += product (alone): `out += lin_r(x_r)` of layers/sage.py:129; the
                           * caller provides the addend (zeros for a plain product)        */
+#define SAGE_EPI_ZEROED 8 /* with SAGE_EPI_ACCUM: the caller promises that the addend is all zeros
+                           * (a buffer its consumer hands back cleared).  Shapes whose output
+                           * elements have one owner are then stored instead of load-add-stored;
+                           * shapes that share an element between workgroups add into it as before,
+                           * without a fill pass.  No counterpart in the reference.          */
 
 /* words of the sampler's device state block (sage_i64 state[SAGE_STATE_WORDS]) */
 #define SAGE_ST_NODES 0      /* number of sampled nodes so far  (len(samples))           */

@@ -301,7 +301,11 @@ def test_linear_dweight2(dev, m, n, k1, k2):
     torch.testing.assert_close(dw2.cpu(), dout[:h].t() @ table[rows[:h]], rtol=RTOL, atol=tol)
 
 
-@pytest.mark.parametrize("m,n,k", [(512, 41, 256), (100, 7, 36), (300, 200, 128), (65, 64, 600)])
+@pytest.mark.parametrize("m,n,k", [(512, 41, 256), (100, 7, 36), (300, 200, 128), (65, 64, 600),
+                                   # few output tiles, long contraction: one grid for both products, split K
+                                   (512, 256, 256), (512, 121, 256), (1000, 300, 100), (70, 128, 130),
+                                   # tiles enough: the two whole-K launches
+                                   (6000, 256, 256)])
 def test_linear_dinput2(dev, m, n, k):
     from graphsage_amd import ops
     g = torch.Generator().manual_seed(m + k)
@@ -321,6 +325,16 @@ def test_fusion_flags(dev):
     accumulate (out += product), clear_dh, clear_z, Adam with zero_grad and a separate step_out."""
     from graphsage_amd import ops
     g = torch.Generator().manual_seed(3)
+    # the zeroed-addend promise gives what out += product gives on zeros, whatever path the shape takes
+    for (m, n, k1, k2) in [(13312, 256, 100, 100), (512, 41, 256, 256), (13000, 256, 602, 602), (3000, 256, 50, 50)]:
+        a1, w1, a2, w2 = _rand((m, k1), g), _rand((n, k1), g), _rand((m, k2), g), _rand((n, k2), g)
+        outs = []
+        for mode in (True, 'zeroed'):
+            out = torch.zeros(m, n, device=dev)
+            ops.linear_concat_fwd(a1.to(dev), w1.to(dev), a2.to(dev), w2.to(dev), out=out, accumulate=mode)
+            outs.append(out.cpu())
+        torch.testing.assert_close(outs[1], a1 @ w1.t() + a2 @ w2.t(), rtol=RTOL, atol=2e-4)
+        torch.testing.assert_close(outs[1], outs[0], rtol=1e-5, atol=1e-5)
     # out += a1 @ w1^T + a2 @ w2^T, small (split-K path) and large (tile path) outputs
     for m, n, k in ((100, 41, 256), (700, 200, 96)):
         a1, a2 = torch.randn(m, k, generator=g), torch.randn(m, k, generator=g)
