@@ -1864,6 +1864,12 @@ static int linear_dweight2_impl(const float* dout, sage_i64 ld_dout, const float
     if (n >= 256 && !(bm_env && bm_env[0] == '6')) {
       const int64_t tiles2 = cdiv(n, 128) * (cdiv(k1, 128) + cdiv(k2, 128));
       int64_t sp = balanced_splits(tiles2, 512, max_splits);
+      // a narrow input (F = 100: 4 tiles) would be cut into 128 slices of 4 K-steps whose every
+      // output element then takes 128 atomics: half as many slices, twice as long, are faster
+      // (40 against 51 us alone, 0.499 against 0.506 ms per products-scale unsupervised step;
+      // SAGE_DW_SPLIT_SLOTS=512: the old rule, the A/B switch)
+      static const char* sp_env = getenv("SAGE_DW_SPLIT_SLOTS");
+      if (tiles2 <= 4) sp = balanced_splits(tiles2, sp_env ? atoi(sp_env) : 256, max_splits);
       g.k_chunk = static_cast<int>(cdiv(cdiv(m, sp), BK) * BK);
       sp = cdiv(m, g.k_chunk);
       if (parts_out != nullptr && sp > 1 && sp <= max_parts) {

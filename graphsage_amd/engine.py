@@ -858,13 +858,12 @@ class SageTrainEngine:
                                       want_argmax=self.reduce == 'max', argmax=a.get('argmax'))
             # The GEMMs ADD into z (stream-K / split-K partial sums), and every z starts as zeros:
             # the consumer hands it back zeroed (clear_z of the normalise kernel, of the fused
-            # loss kernel in the supervised step), so there is no fill kernel.  Only the unsup
-            # variants' logit layer has no clearing consumer.
+            # loss kernel in the supervised step, of the unsup variants' normalise pass), so there is
+            # no fill kernel.
             lib.linear_concat_fwd(agg, layer.lin_l.weight, x if self.root else None,
                                   layer.lin_r.weight if self.root else None, m=t_cap,
                                   m_dev=t_dev, rows2=node_map if self.root else None, out=a['z'],
-                                  accumulate='zeroed' if (i < L - 1 or not self.unsup) and self.zeroed_hint else
-                                  (i < L - 1 or not self.unsup))
+                                  accumulate='zeroed' if self.zeroed_hint else True)
             if i < L - 1 and not (raw_last and i == upto - 1):
                 # (keep_z_last: the backward of that layer works from z, sage_l2norm_relu_bwd_z_dw, and clears it)
                 lib.l2norm_relu_fwd(a['z'], True, m=t_cap, m_dev=t_dev, y=a['y'], h=a['h'], inv_norm=a['inv'],
@@ -906,7 +905,7 @@ class SageTrainEngine:
         for v in range(3):
             self._forward_layers(slot, v, skip_gather0)
             last = self.acts[v][-1]
-            lib.l2norm_relu_fwd(last['z'], False, m=B, y=last['y'], inv_norm=last['inv'])
+            lib.l2norm_relu_fwd(last['z'], False, m=B, y=last['y'], inv_norm=last['inv'], clear_z=True)
         l0, l1, l2 = (self.acts[v][-1] for v in range(3))
         # loss = CE(out, y) + unsup(out, pos_out, neg_out)   (node_level_graphsage_trainers.py:41)
         if self.unsup_only:
