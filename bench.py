@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--serial", action="store_true",
                     help="headline from the serial schedule (every kernel of a step on one stream) instead of "
                          "the overlapped one (layer-0 gather of batch s+1 on the side stream beside batch s)")
+    ap.add_argument("--overlapped", action="store_true",
+                    help="the overlapped schedule also for rows too narrow for the engine's overlap_gather='auto' "
+                         "rule (an A/B switch; one GPU, not the pooling / lstm aggregators)")
     ap.add_argument("--module-path", action="store_true",
                     help="max_pool / mean_pool through the module path (autograd Functions) instead of the engine")
     ap.add_argument("--probe-steps", type=int, default=300,
@@ -566,10 +569,12 @@ def main():
     # One GPU: the overlapped schedule.  Data parallel: the serial one — the layer-0 gather of
     # batch s+1 then sits on the main stream between the all-reduce launch of step s and its
     # Adam step and covers the collective (graphsage_amd/engine.py).
-    # (PPI-sized rows — 50 floats — make every kernel latency-bound: the overlapped schedule's cross-stream
-    # hand-shake then costs more than the 9 us gather it hides, 0.187 against 0.158 ms/step)
+    # (narrow rows — PPI's 50 floats — make every kernel latency-bound: the overlapped schedule's
+    # cross-stream hand-shake then costs more than the gather it hides, 0.187 against 0.158 ms/step;
+    # the three-forward steps run faster serially too: the engine's overlap_gather='auto' rule,
+    # which the trainers use as well)
     overlapped = (not args.serial and not use_graph and not pooling and world == 1 and not force_coll
-                  and args.workload != "ppi")
+                  and (args.overlapped or SageTrainEngine.gather_pays_overlap(Fdim, B, K, bool(unsup))))
     import copy
     # 1. the roofline probe: serial schedule (every kernel of a step on ONE stream), where the
     #    HBM-bound layer-0 gather has the chip to itself and its event-timed duration is its own

@@ -150,6 +150,24 @@ class SageTrainEngine:
       `replay()`.
     """
 
+    @staticmethod
+    def gather_pays_overlap(num_features, batch_size, fanouts, unsup=False):
+        """The overlap_gather='auto' rule.  The side-stream gather costs a cross-stream hand-shake per
+        step and pays when it hides more than that — measured, same box, ms per step overlapped /
+        serial (profiles/r3_schedule_ab.txt):
+          supervised step  Reddit rows (602 floats, 351 MB of gather capacity per batch) 0.213 / 0.225,
+                           products rows (100 floats, 58 MB) 0.097 / 0.103, PPI rows (50 floats, 29 MB) 0.187 / 0.158
+          three forwards   (unsup=True / 'only': one of the three layer-0 gathers can go aside)
+                           Reddit 0.855 / 0.831, products 0.500 / 0.477
+        hence: the supervised step with at least 40 MB of capacity (4 bytes x feature width x sampled edges)."""
+        if unsup:
+            return False
+        frontier, edge_cap = int(batch_size), 0
+        for k in fanouts:
+            frontier *= int(k)
+            edge_cap += frontier
+        return 4 * int(num_features) * edge_cap >= (40 << 20)
+
     def __init__(self, model, sampler, features, labels, batch_size, lr=1e-3, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=0.0, world_size=1, process_group=None, overlap_gather=False,
                  keep_grads=False, group=4, unsup=False, force_collective=False):
@@ -258,10 +276,7 @@ class SageTrainEngine:
         # sample-buffer slots: batch i computes from one while the sampler fills the next; with
         # overlap_gather a third one, because then the sampler runs TWO batches ahead
         if overlap_gather == 'auto':
-            # the side-stream gather costs a cross-stream hand-shake per step (~25 us) and pays when it
-            # hides more than that: Reddit's 602-float rows (340 MB of capacity per batch, 52 us) yes,
-            # PPI's 50-float rows (28 MB, 9 us) no — 0.187 against 0.158 ms per step
-            overlap_gather = 4 * model.layers[0].lin_l.weight.size(1) * edge_cap >= (128 << 20)
+            overlap_gather = self.gather_pays_overlap(model.layers[0].lin_l.weight.size(1), self.B, fan, unsup)
         self.overlap_gather = bool(overlap_gather)
         # Cross-stream events are the expensive part of pipelining on this platform (a wait and
         # a record on the main stream cost ~20 us per step, the sampler kernels beside the

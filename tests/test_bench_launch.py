@@ -41,6 +41,18 @@ def test_self_launch_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_schedule_rule_of_the_engine_and_the_bench():
+    """overlap_gather='auto' (engine, trainers, fig2a, bench.py): the side-stream gather for the
+    supervised step on rows wide enough to pay for the cross-stream hand-shake, the serial schedule
+    for narrow rows and for the three-forward steps (profiles/r3_schedule_ab.txt)."""
+    from graphsage_amd.engine import SageTrainEngine as E
+    assert E.gather_pays_overlap(602, 512, [25, 10]) is True          # Reddit
+    assert E.gather_pays_overlap(100, 512, [25, 10]) is True          # products
+    assert E.gather_pays_overlap(50, 512, [25, 10]) is False          # PPI
+    assert E.gather_pays_overlap(602, 512, [25, 10], unsup=True) is False
+    assert E.gather_pays_overlap(602, 512, [25, 10], unsup='only') is False
+
+
 def test_main_self_launches_only_without_world_size(monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
