@@ -505,6 +505,15 @@ class SageTrainEngine:
         # the stream to the backend — the asynchronous work-handle path)
         self.comm = (new_side_stream(dev, [main, self.side]) if (self.collective and not os.environ.get('SAGE_DP_BACKEND_STREAM'))
                      else None)
+        # the three-forward steps: the positive and the negative variant run on streams of their own
+        # beside the batch's (kernels of 512 to 13 k rows leave most of the chip idle one at a time);
+        # fork behind make_pos_neg, join in front of the loss, fork again for the three backward
+        # passes (their weight gradients meet in fp32 atomics either way), join in front of Adam
+        # (SAGE_NO_UNSUP_FORK=1: one stream, the A/B switch)
+        self.var_streams = None
+        if self.unsup and not os.environ.get('SAGE_NO_UNSUP_FORK'):
+            v1 = new_side_stream(dev, [main, self.side])
+            self.var_streams = [v1, new_side_stream(dev, [main, self.side, v1])]
         self._forked = False
         self.sampled = [torch.cuda.Event() for _ in range(self.nslots)]     # slot sampled (sampler stream)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
@@ -917,10 +926,12 @@ class SageTrainEngine:
             # last layer: normalise + loss on the seed rows + gradient w.r.t. z, one kernel
             self._loss_last(slot, B)
             return
-        for v in range(3):
-            self._forward_layers(slot, v, skip_gather0)
-            last = self.acts[v][-1]
-            lib.l2norm_relu_fwd(last['z'], False, m=B, y=last['y'], inv_norm=last['inv'], clear_z=True)
+        for v in (1, 2, 0):      # (the forked variants first: they start while the host enqueues the batch's)
+            with self._variant(v):
+                self._forward_layers(slot, v, skip_gather0)
+                last = self.acts[v][-1]
+                lib.l2norm_relu_fwd(last['z'], False, m=B, y=last['y'], inv_norm=last['inv'], clear_z=True)
+        self._join_variants()
         l0, l1, l2 = (self.acts[v][-1] for v in range(3))
         # loss = CE(out, y) + unsup(out, pos_out, neg_out)   (node_level_graphsage_trainers.py:41)
         if self.unsup_only:
@@ -933,9 +944,7 @@ class SageTrainEngine:
             lib.unsup_loss(l0['y'], l1['y'], l2['y'], l0['dy'], l1['dy'], l2['dy'], self.row_loss, self.loss_unsup,
                            m=B)
             _lib.tape_py(lambda: torch.add(self.loss_sup, self.loss_unsup, out=self.loss))
-        for v in range(3):
-            last = self.acts[v][-1]
-            lib.l2norm_relu_bwd(last['dy'], last['y'], last['inv'], False, m=B, dz=last['dz'])
+        # (d y -> d z of the three logit layers: the first kernel of each variant's backward pass)
 
     def _loss_last(self, slot, m):
         """normalise + loss over the first m seed rows + d loss / d z: cross entropy on class ids
@@ -951,8 +960,15 @@ class SageTrainEngine:
     def _backward(self, slot, fused=False):
         if self.keep_grads:
             _lib.tape_py(self.grad.zero_)
-        for v in range(3 if self.unsup else 1):
-            self._backward_layers(slot, v, fused)
+        if self.unsup:
+            for v in (1, 2, 0):
+                with self._variant(v):
+                    last = self.acts[v][-1]
+                    ops.l2norm_relu_bwd(last['dy'], last['y'], last['inv'], False, m=self.B, dz=last['dz'])
+                    self._backward_layers(slot, v, fused)
+            self._join_variants()
+        else:
+            self._backward_layers(slot, 0, fused)
         if self._forked:      # everything behind the backward (Adam, the all-reduce) sees the forked gradients
             main = torch.cuda.current_stream()
             _lib.tape_py(lambda: main.wait_stream(self.pool_fork))
@@ -1020,6 +1036,27 @@ class SageTrainEngine:
                     lib.linear_dinput(a['dz'], layer.lin_l.weight, m=t_cap, m_dev=t_dev, out=a['dagg'])
                 lib.gather_reduce_bwd(a['dagg'], buf.seg_ptr, buf.src, t_cap, self.reduce, prev['dh'],
                                       argmax=a.get('argmax'), num_targets_dev=t_dev)
+    @contextlib.contextmanager
+    def _variant(self, v):
+        """Variant v of the three-forward step on its stream (0: the batch itself, on the main stream)."""
+        if v == 0 or self.var_streams is None:
+            yield
+            return
+        st, main = self.var_streams[v - 1], torch.cuda.current_stream()
+        _lib.tape_py(lambda: st.wait_stream(main))
+        torch.cuda.set_stream(st)
+        try:
+            yield
+        finally:
+            torch.cuda.set_stream(main)
+
+    def _join_variants(self):
+        if self.var_streams is None:
+            return
+        main = torch.cuda.current_stream()
+        for st in self.var_streams:
+            _lib.tape_py(lambda st=st: main.wait_stream(st))
+
     @contextlib.contextmanager
     def _leaf(self, rows):
         """Pooling aggregators: the large weight gradients (MFMA-bound) are leaves of the backward,
