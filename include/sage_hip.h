@@ -318,7 +318,12 @@ int sage_linear_dinput(const float* dout, sage_i64 ld_dout, const float* w, sage
 
 /* Both input gradients of a layer in one launch: da1 = dout . w1, da2 = dout . w2 (what autograd
  * derives for out = lin_l(agg) + lin_r(x_r), layers/sage.py:124-129: d agg and d x_r).  Same
- * shapes as sage_linear_dinput; both outputs are overwritten. */
+ * shapes as sage_linear_dinput; both outputs are overwritten (rows at and past *m_dev stay
+ * untouched).  n <= 64: one VALU grid over both products.  Otherwise, when both products together
+ * have at most 128 output tiles of 64 x 128 (the 512 seed rows of a wide last layer), ONE MFMA
+ * grid works on both with the contraction split over blockIdx.z: a fill launch clears the outputs
+ * and the slices add into them with fp32 atomics (summation order varies between runs); larger
+ * shapes run as two whole-K launches. */
 int sage_linear_dinput2(const float* dout, sage_i64 ld_dout, const float* w1, sage_i64 ld_w1,
                         float* da1, sage_i64 ld_da1, const float* w2, sage_i64 ld_w2, float* da2,
                         sage_i64 ld_da2, sage_i64 m, const sage_i64* m_dev, int n, int k,
