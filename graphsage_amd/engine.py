@@ -37,7 +37,12 @@ It computes exactly what GraphSAGE.forward_batch + F.cross_entropy + autograd + 
     (sage_lstm_gather_flat: 0.8 GB at the Reddit shape, static, in 288 GB of HBM), so that the
     gates contraction and its weight gradient are ONE launch per gate block over K = n_in * F with
     both operands contiguous in k — W_ih lives in the flat parameter buffer with padded rows and
-    is never re-laid, its gradient goes straight into the flat gradient, Adam is the fused kernel.
+    is never re-laid, its gradient goes straight into the flat gradient, Adam is the fused kernel;
+  * the trainers' three-forward steps (unsup=True: supervised + unsupervised term, reference
+    trainers/node_level_graphsage_trainers.py:34-46; unsup='only': :104-117) read the positive /
+    negative variants' layer-0 rows through node maps (no second and third batch.x), run those two
+    variants on streams of their own beside the batch's, forward and backward, and take the serial
+    schedule (overlap_gather='auto', gather_pays_overlap()).
 """
 import contextlib
 import ctypes
