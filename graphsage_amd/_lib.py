@@ -17,6 +17,8 @@ SIGNATURES = {
     "sage_last_error": (c_char_p, []),
     "sage_abi_version": (c_int, []),
     "sage_probe_next_contraction": (c_int, [_P, _P, c_int]),
+    "sage_event_record": (c_int, [_P, _P]),
+    "sage_stream_wait_event": (c_int, [_P, _P]),
     "sage_csc_build_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "sage_csc_build": (c_int, [_P, _P, c_int64, c_int64, _P, _P, _P, _P, c_size_t, _P]),
     "sage_sample_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -52,5 +52,19 @@ extern "C" int sage_probe_next_contraction(void* start_event, void* stop_event, 
   return SAGE_OK;
 }
 
+extern "C" int sage_event_record(void* event, void* stream) {
+  SAGE_REQUIRE(event != nullptr, SAGE_EINVAL, "sage_event_record: NULL event");
+  const hipError_t e = hipEventRecord(static_cast<hipEvent_t>(event), static_cast<hipStream_t>(stream));
+  SAGE_REQUIRE(e == hipSuccess, SAGE_ELAUNCH, "sage_event_record: %s", hipGetErrorString(e));
+  return SAGE_OK;
+}
+
+extern "C" int sage_stream_wait_event(void* stream, void* event) {
+  SAGE_REQUIRE(event != nullptr, SAGE_EINVAL, "sage_stream_wait_event: NULL event");
+  const hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0);
+  SAGE_REQUIRE(e == hipSuccess, SAGE_ELAUNCH, "sage_stream_wait_event: %s", hipGetErrorString(e));
+  return SAGE_OK;
+}
+
 extern "C" const char* sage_last_error(void) { return sage::g_err; }
 extern "C" int sage_abi_version(void) { return 2; }

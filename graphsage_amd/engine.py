@@ -519,6 +519,11 @@ class SageTrainEngine:
         if self.unsup and not os.environ.get('SAGE_NO_UNSUP_FORK'):
             v1 = new_side_stream(dev, [main, self.side])
             self.var_streams = [v1, new_side_stream(dev, [main, self.side, v1])]
+            # fork and join through events of the engine's own, recorded and waited for by library
+            # calls on the step's tape (one record + two waits to fork, two + two to join: ~10 us of
+            # host time per step for both phases; four stream-to-stream waits of the host framework
+            # per phase were 120 us and left the products-scale step host-bound)
+            self.var_ev = [ops.new_event(main), ops.new_event(v1), ops.new_event(self.var_streams[1])]
         self._forked = False
         self.sampled = [torch.cuda.Event() for _ in range(self.nslots)]     # slot sampled (sampler stream)
         self.ready = [torch.cuda.Event() for _ in range(self.nslots)]   # slot sampled (side stream)
@@ -1048,7 +1053,9 @@ class SageTrainEngine:
             yield
             return
         st, main = self.var_streams[v - 1], torch.cuda.current_stream()
-        _lib.tape_py(lambda: st.wait_stream(main))
+        if v == 1:      # (first of the forked variants: the fork point of both)
+            ops.event_record(self.var_ev[0], main)
+        ops.stream_wait_event(st, self.var_ev[0])
         torch.cuda.set_stream(st)
         try:
             yield
@@ -1059,8 +1066,9 @@ class SageTrainEngine:
         if self.var_streams is None:
             return
         main = torch.cuda.current_stream()
-        for st in self.var_streams:
-            _lib.tape_py(lambda st=st: main.wait_stream(st))
+        for k, st in enumerate(self.var_streams):
+            ops.event_record(self.var_ev[1 + k], st)
+            ops.stream_wait_event(main, self.var_ev[1 + k])
 
     @contextlib.contextmanager
     def _leaf(self, rows):

@@ -36,6 +36,25 @@ def _p(t, dtype, name, allow_none=False):
     return c_void_p(t.data_ptr())
 
 
+def new_event(stream=None):
+    """A torch event whose HIP handle exists (torch creates it at the first record)."""
+    ev = torch.cuda.Event()
+    ev.record(stream if stream is not None else torch.cuda.current_stream())
+    return ev
+
+
+def event_record(ev, stream):
+    """hipEventRecord(ev, stream) as a library call: an entry of a recorded call tape."""
+    rc = _lib.load().sage_event_record(c_void_p(ev.cuda_event), c_void_p(stream.cuda_stream))
+    _lib.check(rc, "sage_event_record")
+
+
+def stream_wait_event(stream, ev):
+    """hipStreamWaitEvent(stream, ev) as a library call: an entry of a recorded call tape."""
+    rc = _lib.load().sage_stream_wait_event(c_void_p(stream.cuda_stream), c_void_p(ev.cuda_event))
+    _lib.check(rc, "sage_stream_wait_event")
+
+
 def empty_rows(m, n, device, dtype=torch.float32, zero=False):
     """[m, n] matrix whose rows start 64-byte aligned: a view of a buffer with the row stride
     rounded up to 16 elements when n is not a multiple of 4 (e.g. 602 -> 608), so that every

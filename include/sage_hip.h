@@ -87,6 +87,14 @@ int sage_abi_version(void);
  * (SAGE_ELIMIT); (NULL, NULL) cancels all pending pairs.  The skinny VALU kernels and the
  * zero-fill launches do not count. */
 int sage_probe_next_contraction(void* start_event, void* stop_event, int skip);
+/* Cross-stream ordering for callers that replay recorded call sequences over several streams
+ * (graphsage_amd/engine.py: the forked variants of the three-forward steps): hipEventRecord /
+ * hipStreamWaitEvent on caller-owned handles, so that the fork and the join are entries of the
+ * same call tape as the kernels between them (2.6 us and 0.3 us of host time; the host
+ * framework's stream-to-stream wait creates, records and destroys an event per call: 15 us).
+ * No counterpart in the reference.  SAGE_EINVAL for a NULL event, SAGE_ELAUNCH if HIP refuses. */
+int sage_event_record(void* event, void* stream);
+int sage_stream_wait_event(void* stream, void* event);
 
 /* ------------------------------------------------------------------------------------
  * (a-1) CSC build.  Replaces torch_geometric.loader.utils.to_csc(data, device='cpu')
