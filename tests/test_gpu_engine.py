@@ -300,3 +300,37 @@ def test_evaluate_pipeline_matches_module_inference(dev, aggregator, overlap, mo
             ref_engine.flat.copy_(engine.flat)
         else:
             assert_trajectories_close(engine.flat, ref_engine.flat)
+
+
+def test_event_record_and_stream_wait_order_two_streams(dev):
+    """sage_event_record / sage_stream_wait_event (the fork and join of the forked variants): work
+    enqueued on stream b behind the wait sees what stream a wrote in front of the record, both as
+    direct calls and replayed from a recorded tape."""
+    from graphsage_amd import _lib, ops
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = ops.new_event()
+    x = torch.zeros(1 << 20, device=dev)
+    y = torch.zeros(1 << 20, device=dev)
+    torch.cuda.synchronize()
+
+    def round_trip(tape=None):
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(5_000_000)           # a few ms: b would run ahead without the wait
+            x.add_(1.0)
+        if tape is None:
+            ops.event_record(ev, a)
+            ops.stream_wait_event(b, ev)
+        else:
+            _lib.replay(tape)
+        with torch.cuda.stream(b):
+            y.copy_(x * 2.0)
+        torch.cuda.synchronize()
+
+    with _lib.recording() as tape:
+        round_trip()
+    assert len(tape) == 2 and float(y.min()) == 2.0 and float(y.max()) == 2.0
+    round_trip(tape)
+    assert float(y.min()) == 4.0 and float(y.max()) == 4.0
+    lib = _lib.load()
+    assert lib.sage_event_record(None, None) == -1 and "NULL event" in _lib.last_error()
+    assert lib.sage_stream_wait_event(None, None) == -1
