@@ -334,3 +334,44 @@ def test_event_record_and_stream_wait_order_two_streams(dev):
     lib = _lib.load()
     assert lib.sage_event_record(None, None) == -1 and "NULL event" in _lib.last_error()
     assert lib.sage_stream_wait_event(None, None) == -1
+
+
+@pytest.mark.parametrize("aggregator,unsup", [("mean", False), ("max", False), ("gcn", False), ("max_pool", False),
+                                              ("mean_pool", False), ("mean", True), ("mean", "only"), ("max", "only")])
+def test_engine_hands_its_accumulation_buffers_back_zeroed(dev, aggregator, unsup):
+    """The promise behind SAGE_EPI_ZEROED and behind the scatter-adds of the backward: after a
+    step — and after an evaluation pass — every pre-activation buffer z and every hidden-gradient
+    buffer dh of every variant holds zeros again (their consumers clear what they read)."""
+    from graphsage_amd.datasets import planted_partition
+    from graphsage_amd.engine import SageTrainEngine
+    from graphsage_amd.models import GraphSAGE
+    from graphsage_amd.samplers import NeighborSampler
+    from graphsage_amd.samplers.uniform_loader import device_graph
+    data = planted_partition(3000, 60000, 40, 6, seed=2)
+    B = 64
+    torch.manual_seed(0)
+    model = GraphSAGE(40, 32, aggregator, 3, 6).to(dev)
+    graph = device_graph(data)
+    engine = SageTrainEngine(model, NeighborSampler(data, [5, 3, 2], seed=7), graph.features(data),
+                             graph.labels(data), B, lr=1e-2, unsup=unsup)
+    assert engine.zeroed_hint
+
+    def check(when):
+        for v, act in enumerate(engine.acts):
+            for i, a in enumerate(act):
+                for name in ("z", "dh"):
+                    t = a.get(name)
+                    if t is not None:
+                        assert not bool(t.any()), (when, "variant", v, "layer", i, name)
+
+    for b in range(3):
+        engine.step(torch.arange(b * B, (b + 1) * B, device=dev), counter=b)
+        torch.cuda.synchronize()
+        check("after step %d" % b)
+    if not unsup:
+        engine.evaluate(torch.arange(5 * B + 17, device=dev))
+        torch.cuda.synchronize()
+        check("after evaluate")
+        engine.step(torch.arange(B, device=dev), counter=9)
+        torch.cuda.synchronize()
+        check("after the step behind evaluate")
