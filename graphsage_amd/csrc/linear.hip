@@ -1825,7 +1825,49 @@ static int linear_dweight2_impl(const float* dout, sage_i64 ld_dout, const float
     SAGE_CHECK_LAUNCH("skinny_dweight_kernel(pair)");
     return SAGE_OK;
   }
-  if (k1 <= 64 || k2 <= 64) {  // narrow inputs: the single-problem tile shapes are better
+  static const char* narrow_env = getenv("SAGE_DW2_NARROW_SERIAL");      // "1": two launches (the A/B switch)
+  if (k1 <= 64 && k2 <= 64 && !(narrow_env && narrow_env[0] == '1')) {
+    // narrow inputs on both sides (PPI's 50 features): both problems in one grid of 64 x 64 tiles
+    // (two launches of 416 workgroups took 12 + 9.5 us, one of 768 takes 12)
+    GemmArgs g = {};
+    g.seg[0].a = {dout, ld_dout, nullptr, op_vec(dout, ld_dout, n)};
+    g.seg[0].b = {a1, ld_a1, rows1, op_vec(a1, ld_a1, k1)};
+    g.seg[0].k = static_cast<int>(m);
+    g.seg[1].a = g.seg[0].a;
+    g.seg[1].b = {a2, ld_a2, rows2, op_vec(a2, ld_a2, k2)};
+    g.seg[1].k = static_cast<int>(m);
+    g.nseg = 2;
+    g.batched = 1;
+    g.m = n;
+    g.k_dev = m_dev;
+    g.n = k1;
+    g.out = dw1;
+    g.ld_out = ld_dw1;
+    g.n2 = k2;
+    g.out2 = dw2;
+    g.ld_out2 = ld_dw2;
+    g.ny0 = 1;
+    g.atomic_out = 1;
+    const int64_t tiles = cdiv(n, 64) * 2;
+    int64_t splits = 768 / tiles;   // one full round at 3 resident workgroups per CU
+    const int64_t max_splits = cdiv(m, 4 * BK);
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
+    splits = cdiv(m, g.k_chunk);
+    int vec = 4;
+    for (int sgi = 0; sgi < 2; ++sgi) {
+      if (g.seg[sgi].a.vec < vec) vec = g.seg[sgi].a.vec;
+      if (g.seg[sgi].b.vec < vec) vec = g.seg[sgi].b.vec;
+    }
+    const dim3 grid(static_cast<unsigned>(cdiv(n, 64)), 2, static_cast<unsigned>(splits));
+    if (vec == 4) SAGE_LAUNCH_PROBED((gemm_kernel<false, false, 64, 64, 4>), grid, kThreads, stream, g);
+    else if (vec == 2) SAGE_LAUNCH_PROBED((gemm_kernel<false, false, 64, 64, 2>), grid, kThreads, stream, g);
+    else SAGE_LAUNCH_PROBED((gemm_kernel<false, false, 64, 64, 1>), grid, kThreads, stream, g);
+    SAGE_CHECK_LAUNCH("gemm_kernel(dweight2, narrow pair)");
+    return SAGE_OK;
+  }
+  if (k1 <= 64 || k2 <= 64) {  // one narrow input: the single-problem tile shapes are better
     int rc = sage_linear_dweight(dout, ld_dout, a1, ld_a1, rows1, m, m_dev, n, k1, dw1, ld_dw1, nullptr, stream_);
     if (rc != SAGE_OK) return rc;
     return sage_linear_dweight(dout, ld_dout, a2, ld_a2, rows2, m, m_dev, n, k2, dw2, ld_dw2, nullptr, stream_);

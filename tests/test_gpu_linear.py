@@ -281,6 +281,8 @@ def test_logits_xent_fused_matches_three_kernels(dev):
 
 @pytest.mark.parametrize("m,n,k1,k2", [(3000, 256, 602, 602), (700, 96, 130, 300), (512, 41, 256, 256),
                                        (300, 7, 100, 520), (90, 200, 40, 300),
+                                       # narrow inputs on both sides: one grid of 64 x 64 tiles for the pair
+                                       (13100, 256, 50, 50), (700, 121, 64, 33), (200, 96, 7, 50),
                                        # full-size contraction, 16-byte-aligned operands
                                        (13100, 256, 608, 602), (5000, 128, 132, 300)])
 def test_linear_dweight2(dev, m, n, k1, k2):
