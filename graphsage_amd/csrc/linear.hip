@@ -1588,8 +1588,13 @@ static int linear_concat_fwd_impl(const float* a1, sage_i64 ld_a1, const sage_i6
       return SAGE_OK;
     }
   }
+  // (short contractions — PPI's 50 + 50 features: 4 K-steps per tile — stay whole tiles, as in the
+  // bf16x3 mode above: a piece of 3 steps with an atomic epilogue is no faster than a tile of 4 with
+  // plain stores; SAGE_FWD_STREAMK_SHORT=1: stream-K for them too, the A/B switch)
+  static const char* sk_short_env = getenv("SAGE_FWD_STREAMK_SHORT");
+  const bool short_k = cdiv(k1, BK) + cdiv(k2, BK) <= 12 && !(sk_short_env && sk_short_env[0] == '1');
   if ((epilogue & ~SAGE_EPI_ACCUM) == SAGE_EPI_NONE && n > 64 && slots > 0 && tiles > slots / 2 &&
-      tiles * 10 < cdiv(tiles, slots) * slots * 9) {
+      tiles * 10 < cdiv(tiles, slots) * slots * 9 && !short_k) {
     g.streamk = 1;
     g.atomic_out = accum ? 1 : 0;   // out += product: whole tiles are added too
     if (!accum) zero_rows_kernel<<<static_cast<unsigned>(cdiv(m * n, kThreads)), kThreads, 0, stream>>>(out, ld_out, m, n);
