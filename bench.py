@@ -578,8 +578,11 @@ def main():
     import copy
     # 1. the roofline probe: serial schedule (every kernel of a step on ONE stream), where the
     #    HBM-bound layer-0 gather has the chip to itself and its event-timed duration is its own
+    #    (also when the headline schedule is the serial one — narrow rows, data parallel: the event
+    #    pairs then stay out of the timed region that `value` comes from; on PPI-sized steps they cost
+    #    10 us per step, and at N > 1 they would count against the scaling)
     probe_res = None
-    if probe and overlapped:
+    if probe and not use_graph:
         pm = copy.deepcopy(model)
         probe_res = run_schedule(make_engine(pm, False), base, args.warmup, max(1, min(args.probe_steps, args.steps)), True)
         base_main = min(base, 300)       # the process is warm now
@@ -588,7 +591,9 @@ def main():
     # 2. the headline run
     engine = make_engine(model, overlapped)
     setup_s = time.perf_counter() - t_setup
-    res = run_schedule(engine, base_main, args.warmup, args.steps, probe, graph_replay=use_graph)
+    #    (no event pairs in its timed region: the products-shaped step loses 0.02 ms to them, the
+    #    headline 0.002; only the graph replay, which has no separate probe run, carries them)
+    res = run_schedule(engine, base_main, args.warmup, args.steps, probe and use_graph, graph_replay=use_graph)
     elapsed, st, loss = res["elapsed"], res["st"], res["loss"]
     # the drain after the timed region sampled nothing new, but keep the counts exact anyway:
     # ST sums cover the timed steps because prefetches of the drain are not issued (no next_seeds)
@@ -679,9 +684,12 @@ def main():
             if probe_res is not None:
                 # the same kernel in the headline (overlapped) schedule, where it shares the chip with
                 # the MFMA-bound forward GEMM of the previous batch: longer by contention, not by itself
-                oms = res["gather_ms"]
                 roofline["serial_ms_per_step"] = round(probe_res["elapsed"] / n_launch * 1e3, 4)
-                roofline["overlapped_avg_launch_us"] = round(float(oms.mean()) * 1e3, 2)
+                if overlapped:
+                    # (a short run of the headline schedule with the event pairs attached, behind the timed one)
+                    n_ov = max(1, min(200, args.steps))
+                    r_ov = run_schedule(make_engine(copy.deepcopy(model), True), 50, args.warmup, n_ov, True)
+                    roofline["overlapped_avg_launch_us"] = round(float(r_ov["gather_ms"].mean()) * 1e3, 2)
         # Informational only (never `value`): the headline schedule with the big contractions on the
         # exact-fp32 MFMA (SAGE_GEMM_X3=0) instead of the default bf16x3 split
         variant_f32 = None
