@@ -411,15 +411,17 @@ class SageTrainEngine:
                         a['rest_dev'] = torch.zeros(1, dtype=torch.int64, device=dev)   # live targets behind the seeds
                 if i > 0 or self.pool or self.lstm:
                     a['dagg'] = padded(t_cap, fin)
-                    if (self.lstm and i == 0 and t_cap >= 4096 and fin >= 256
+                    if ((self.lstm or self.pool) and i == 0 and t_cap >= 4096 and fin >= 256
                             and not os.environ.get('SAGE_NO_DAGG_X3')):
                         # layer 0's d agg = dz . W_l as a FORWARD-type contraction on a transposed copy
                         # of W_l (both operands contiguous in the contracted index: the bf16x3 kernel
-                        # takes it; the d-input kernel is exact-fp32 only, 69 us at the Reddit shape):
-                        # lstm 9.12 against 9.18 ms per step.  Not for the pooling aggregators: there
-                        # this contraction runs beside the forked weight gradients and the same-box A/B
-                        # went the other way (max_pool 1.209 against 1.200 ms, mean_pool 1.310 / 1.307;
-                        # scratch/dagg_ab.sh) — VERDICT r2 item 6's first half, measured and not kept
+                        # takes it; the d-input kernel is exact-fp32 only, 55-69 us at the Reddit shape):
+                        # lstm 9.12 against 9.18 ms per step.  For the pooling aggregators, where this
+                        # contraction runs beside the forked weight gradients, the same-box A/B first went
+                        # the other way (max_pool 1.209 against 1.200 ms with the pushed edge pass behind
+                        # it, scratch/dagg_ab.sh); with the pulled edge pass and the fused last layer it
+                        # pays: max_pool 1.143 against 1.156, mean_pool 1.183 against 1.197
+                        # (scratch/pool_dagg_ab2.sh, profiles/r3_pool_dagg_ab.txt; SAGE_NO_DAGG_X3=1)
                         a['wlT'] = padded(fin, fout)
                     if self.reduce == 'max':   # the backward routes to the edge that attained the max
                         a['argmax'] = torch.zeros((t_cap, fin), dtype=torch.int64, device=dev)
@@ -1143,6 +1145,9 @@ class SageTrainEngine:
             lib.linear_dweight(a['dpre'], x_in, m=s_cap, m_dev=s_dev, rows=rows,
                                dw=self.gviews[layer.pool.weight], dbias=self.gviews[layer.pool.bias])
         if i > 0:
+            # (as a forward-type bf16x3 contraction on a transposed copy of the weights, like layer 0's
+            # d agg, this one is slower: it ADDS into dh — max_pool 1.172 against 1.155 ms, mean_pool
+            # 1.215 against 1.198, scratch/pool_din_ab.sh)
             lib.linear_dinput(a['dpre'], layer.pool.weight, m=s_cap, m_dev=s_dev, out=self.act[i - 1]['dh'],
                               accumulate=True)
 
