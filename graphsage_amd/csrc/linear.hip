@@ -1786,6 +1786,9 @@ extern "C" int sage_linear_dweight(const float* dout, sage_i64 ld_dout, const fl
   if (splits < 1) splits = 1;
   g.k_chunk = static_cast<int>(cdiv(cdiv(m, splits), BK) * BK);
   splits = cdiv(m, g.k_chunk);
+  // (m >= 2,048 contracted rows: the lstm cell's weight gradient over the 512 seed rows — 1,204 x
+  // 15,050 outputs, 18 GFLOP — was tried here on its flop count and is slower than on the exact-fp32
+  // kernel, 5.07 against 5.00 ms per lstm step: 16 K-steps per tile do not pay for the split)
   if (x3_mode() && k > 64 && g.seg[0].a.vec == 4 && g.seg[0].b.vec == 4 && m >= 64 * BK) {
     g.xcd_map = xcd_mode() ? 1 : 0;
     const char* bm_env = getenv("SAGE_GEMM_BM");      // "64": keep the 64-row tile (A/B switch)
